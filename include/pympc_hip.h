@@ -1,0 +1,110 @@
+/*
+ * pympc_hip.h -- C ABI of the MI355X (gfx950) batched QP/LP path behind pympc's pnnls backend.
+ *
+ * The reference (pure Python) has no FFI; the interface every entry point replaces is the backend
+ * contract of pympc/optimization/solvers/pnnls.py (same signatures in gurobi.py:5,60 / drake.py:6,95)
+ * reached through pympc/optimization/programs.py:9,57.  Each declaration cites the reference lines
+ * whose loop it batches.  INTEGRATION.md shows the ctypes stub a pympc maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp64 (or int32/uint32) memory owned by
+ *     the caller (torch tensors on the host side); `stream` is a hipStream_t passed as void*.
+ *   - entry points allocate nothing and never synchronise; kernels are asynchronous on `stream`.
+ *   - return value: 0 on success, < 0 on argument / launch errors (pympc_hip_last_error() has the text).
+ *   - per-problem status codes are written to device memory:
+ *       PYMPC_OPTIMAL     0   solution written
+ *       PYMPC_INFEASIBLE  1   QP infeasible / LP infeasible or unbounded: the reference returns a sol
+ *                             dict of None (pnnls.py:128-134, 221-227); outputs are NaN / zero bits
+ *       PYMPC_MAXITER     3   NNLS hit 3*cols iterations (scipy raises RuntimeError there)
+ *       PYMPC_NOT_PD      4   Hessian not positive definite (numpy.linalg.LinAlgError at pnnls.py:210)
+ */
+#ifndef PYMPC_HIP_H
+#define PYMPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYMPC_OPTIMAL 0
+#define PYMPC_INFEASIBLE 1
+#define PYMPC_MAXITER 3
+#define PYMPC_NOT_PD 4
+
+#define PYMPC_ERR_ARG (-1)
+#define PYMPC_ERR_UNSUPPORTED (-2)
+#define PYMPC_ERR_LAUNCH (-3)
+
+/* ABI version (bumped on any signature change). */
+int pympc_hip_abi_version(void);
+
+/* Text of the last error returned by an entry point on this thread. */
+const char *pympc_hip_last_error(void);
+
+/* Largest problem the wave-per-problem QP kernels accept: n <= *n_max variables, m <= *m_max rows. */
+void pympc_hip_limits(int *n_max, int *m_max);
+
+/* -------------------------------------------------------------------------------------------------
+ * Shared-matrix batched QP: MultiParametricQuadraticProgram.solve(x) for a batch of states.
+ * Reference: pympc/optimization/parametric_programs.py:155-179 (f = Hux x + fu, b = b - Ax x,
+ * quadratic_program, lift of min) -> pympc/optimization/solvers/pnnls.py:149-241, looped by
+ * pympc/control/controllers.py:76-124 (feedforward / feedback).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Number of doubles of caller-owned device workspace `ws` that pympc_mpqp_prepare fills. */
+size_t pympc_mpqp_workspace_doubles(int n, int m, int p);
+
+/*
+ * One-time factorisation of the constant part (hoists pnnls.py:210-214 out of the per-state loop):
+ * L = chol(Huu), L^-1, Huu^-1, M = Au L^-T, and the affine maps m(x) = b(x) + Au Huu^-1 f(x),
+ * u_unc(x) = -Huu^-1 f(x).   Huu [n x n], Hux [n x p], Hxx [p x p], fu [n], fx [p], g scalar (host value),
+ * Au [m x n], Ax [m x p], b [m].   ws_status (1 int32, device) receives PYMPC_OPTIMAL or PYMPC_NOT_PD.
+ */
+int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux, const double *Hxx, const double *fu,
+                       const double *fx, double g, const double *Au, const double *Ax, const double *b, double *ws,
+                       int32_t *ws_status, void *stream);
+
+/*
+ * Solve the QP at each of the B states X [B x p].  Outputs (any pointer except status may be NULL):
+ *   argmin  [B x n_out]   first n_out entries of the minimiser (n_out = n for feedforward, nu for feedback)
+ *   vmin    [B]           lifted optimal value (parametric_programs.py:177)
+ *   mult    [B x m]       multiplier_inequality (pnnls.py:232)
+ *   active  [B x ceil(m/32)] uint32 bit j of word j/32 set iff multiplier j > tol (pnnls.py:235)
+ *   status  [B]           PYMPC_OPTIMAL / PYMPC_INFEASIBLE / PYMPC_MAXITER
+ *   iters   [B x 2]       (outer, inner) NNLS iteration counters (roofline accounting)
+ */
+int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *X, int64_t B, double tol, int n_out,
+                           double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
+                           int32_t *iters, void *stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * Per-problem batched QP: B independent problems  min .5 x'H_k x + f_k'x  s.t. A_k x <= b_k  of equal
+ * shape (n, m); equalities are folded by the caller as rows (C, -C) exactly as pnnls.py:202-207 does.
+ * Reference: pympc/optimization/solvers/pnnls.py:149-241 once per problem (programs.py:57-105); callers
+ * polyhedron.py:523 (empty), controllers.py:668-680 + parametric_programs.py:173 (get_mpqp(ms).solve).
+ * H [B x n x n] (or [n x n] with h_stride 0), f [B x n], A [B x m x n] (a_stride 0: shared), b [B x m].
+ * ------------------------------------------------------------------------------------------------- */
+size_t pympc_qp_workspace_doubles(int n, int m, int64_t B);
+
+int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_stride, const double *f, const double *A,
+                         int64_t a_stride, const double *b, double tol, double *ws, double *argmin, double *vmin,
+                         double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * Explicit-MPC point location + affine law: first critical region (list order) containing each point.
+ * Reference: pympc/optimization/parametric_programs.py:442-463 (get_critical_region), :465-532 (u, V),
+ * :349-400 (CriticalRegion.u / V), pympc/geometry/polyhedron.py:578-604 (contains, tol 1e-7).
+ * Table: region r owns rows row_ptr[r] .. row_ptr[r+1]-1 of A [R x p], b [R]; laws ux [nreg x nu x p],
+ * u0 [nreg x nu] (first nu rows of the region's law), Vxx [nreg x p x p], Vx [nreg x p], V0 [nreg].
+ * Outputs: idx [B] int32 (-1 when uncovered), u [B x nu] (NaN when uncovered), V [B] (NaN when uncovered).
+ * ------------------------------------------------------------------------------------------------- */
+int pympc_point_location(int nreg, int p, int nu, const double *A, const double *b, const int32_t *row_ptr,
+                         const double *ux, const double *u0, const double *Vxx, const double *Vx, const double *V0,
+                         const double *X, int64_t B, double tol, int32_t *idx, double *u, double *V, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYMPC_HIP_H */

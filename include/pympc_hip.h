@@ -96,13 +96,15 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
  * Explicit-MPC point location + affine law: first critical region (list order) containing each point.
  * Reference: pympc/optimization/parametric_programs.py:442-463 (get_critical_region), :465-532 (u, V),
  * :349-400 (CriticalRegion.u / V), pympc/geometry/polyhedron.py:578-604 (contains, tol 1e-7).
- * Table: region r owns rows row_ptr[r] .. row_ptr[r+1]-1 of A [R x p], b [R]; laws ux [nreg x nu x p],
+ * Table: region r owns rows row_ptr[r] .. row_ptr[r+1]-1 of A [total_rows x p], b [total_rows]
+ * (total_rows = row_ptr[nreg], passed by the host so that nothing is read back); laws ux [nreg x nu x p],
  * u0 [nreg x nu] (first nu rows of the region's law), Vxx [nreg x p x p], Vx [nreg x p], V0 [nreg].
  * Outputs: idx [B] int32 (-1 when uncovered), u [B x nu] (NaN when uncovered), V [B] (NaN when uncovered).
  * ------------------------------------------------------------------------------------------------- */
-int pympc_point_location(int nreg, int p, int nu, const double *A, const double *b, const int32_t *row_ptr,
-                         const double *ux, const double *u0, const double *Vxx, const double *Vx, const double *V0,
-                         const double *X, int64_t B, double tol, int32_t *idx, double *u, double *V, void *stream);
+int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
+                         const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
+                         const double *Vx, const double *V0, const double *X, int64_t B, double tol, int32_t *idx,
+                         double *u, double *V, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+// Explicit-MPC point location + affine law evaluation (one state per lane).
+//
+// Reference semantics (/root/reference/pympc/optimization/parametric_programs.py:442-463): scan the critical
+// regions in list order and take the FIRST one whose polyhedron contains x, where contains is
+// max(A x - b) <= tol (/root/reference/pympc/geometry/polyhedron.py:596, tol = 1e-7); then
+// u = ux x + u0 (parametric_programs.py:364) and V = .5 x'Vxx x + Vx'x + V0 (:398); uncovered points give None.
+//
+// MI355X mapping: the streaming side is HBM-bound (p doubles in, 4 + 8 nu + 8 bytes out per point, coalesced),
+// the table side is kept out of HBM: all region rows (A | b) are staged once per workgroup in LDS and every lane
+// of a wavefront scans the SAME region row at the same time, so each ds_read is a broadcast (no bank conflicts).
+// A region is abandoned as soon as every still-searching lane of the wave has violated one of its rows, and the
+// scan stops when every lane has found its region; neighbouring grid points mostly share regions, so the wave
+// rarely does more rows than its slowest lane needs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pympc {
+
+struct PlParams {
+    int nreg, p, nu, total_rows, table_in_lds;
+    const double *A, *b;
+    const int32_t *row_ptr;
+    const double *ux, *u0, *Vxx, *Vx, *V0;
+    const double *X;
+    long long B;
+    double tol;
+    int32_t *idx;
+    double *u, *V;
+};
+
+template <int PD>
+__global__ void point_location_kernel(PlParams P)
+{
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const double *At = P.A, *bt = P.b;
+    if (P.table_in_lds) {
+        const int na = P.total_rows * PD;
+        for (int e = tid; e < na; e += blockDim.x) lds[e] = P.A[e];
+        for (int e = tid; e < P.total_rows; e += blockDim.x) lds[na + e] = P.b[e];
+        __syncthreads();
+        At = lds;
+        bt = lds + na;
+    }
+    const double nanv = __builtin_nan("");
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // every lane of a wave runs the same number of grid-stride rounds (wave-uniform loop bound)
+    const long long base0 = (long long)blockIdx.x * blockDim.x + (tid & ~63);
+    for (long long base = base0; base < P.B; base += stride) {
+        const long long pt = base + (tid & 63);
+        const bool valid = pt < P.B;
+        double x[PD];
+#pragma unroll
+        for (int q = 0; q < PD; ++q) x[q] = valid ? P.X[pt * PD + q] : 0.0;
+        int found = -1;
+        for (int r = 0; r < P.nreg; ++r) {
+            const bool searching = valid && found < 0;
+            if (__ballot(searching) == 0ull) break;
+            bool inside = searching;
+            const int i1 = P.row_ptr[r + 1];
+            for (int i = P.row_ptr[r]; i < i1; ++i) {
+                double s = -bt[i];
+#pragma unroll
+                for (int q = 0; q < PD; ++q) s = fma(At[i * PD + q], x[q], s);
+                inside = inside && (s <= P.tol);
+                if ((i & 3) == 3 && __ballot(inside) == 0ull) break;
+            }
+            if (inside) found = r;
+        }
+        if (valid) {
+            P.idx[pt] = found;
+            double V = nanv;
+            if (found >= 0) {
+                double qd = 0.0, lin = 0.0;
+#pragma unroll
+                for (int i = 0; i < PD; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) s = fma(x[q], P.Vxx[((size_t)found * PD + q) * PD + i], s);
+                    qd = fma(s, x[i], qd);
+                    lin = fma(P.Vx[(size_t)found * PD + i], x[i], lin);
+                }
+                V = .5 * qd + lin + P.V0[found];
+            }
+            P.V[pt] = V;
+            for (int i = 0; i < P.nu; ++i) {
+                double s = nanv;
+                if (found >= 0) {
+                    s = P.u0[(size_t)found * P.nu + i];
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) s = fma(P.ux[((size_t)found * P.nu + i) * PD + q], x[q], s);
+                }
+                P.u[pt * P.nu + i] = s;
+            }
+        }
+    }
+}
+
+}  // namespace pympc

@@ -1,0 +1,253 @@
+// C ABI of the gfx950 batched QP path (declarations and reference citations: include/pympc_hip.h).
+// Plain HIP runtime only: callers hand in device pointers and a stream; nothing here allocates or synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/pympc_hip.h"
+#include "point_location.hpp"
+#include "qp_prepare.hpp"
+#include "qp_wave.hpp"
+#include "ws_layout.hpp"
+
+using namespace pympc;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr size_t kLdsBytes = 160 * 1024;   // MI355X: 160 KiB LDS per CU, a single workgroup may own all of it
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+template <int MT, bool SHARED>
+int launch_solve_mt(const SolveParams &P, int nwaves, size_t lds_bytes, long long nwg, hipStream_t st)
+{
+    auto kernel = qp_solve_kernel<MT, SHARED>;
+    if (int rc = allow_lds(kernel, lds_bytes)) return rc;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(64 * nwaves), lds_bytes, st, P);
+    return check_launch("qp_solve_kernel");
+}
+
+template <bool SHARED>
+int launch_solve(int mt, const SolveParams &P, int nwaves, size_t lds_bytes, long long nwg, hipStream_t st)
+{
+    switch (mt) {
+    case 1: return launch_solve_mt<1, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 2: return launch_solve_mt<2, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 3: return launch_solve_mt<3, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 4: return launch_solve_mt<4, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 6: return launch_solve_mt<6, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 8: return launch_solve_mt<8, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 12: return launch_solve_mt<12, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 16: return launch_solve_mt<16, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 24: return launch_solve_mt<24, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    case 32: return launch_solve_mt<32, SHARED>(P, nwaves, lds_bytes, nwg, st);
+    }
+    return fail(PYMPC_ERR_UNSUPPORTED, "no kernel for %d columns per lane", mt);
+}
+
+int check_shape(int n, int m, int p)
+{
+    if (n < 1 || m < 1 || p < 0) return fail(PYMPC_ERR_ARG, "bad shape n=%d m=%d p=%d", n, m, p);
+    if (n > kNMax) return fail(PYMPC_ERR_UNSUPPORTED, "n=%d exceeds the wave kernel's limit of %d variables", n, kNMax);
+    if (m > kMMax) return fail(PYMPC_ERR_UNSUPPORTED, "m=%d exceeds the wave kernel's limit of %d rows", m, kMMax);
+    return 0;
+}
+
+// Common launch geometry of the solve kernel.
+int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t st)
+{
+    const int R = n + 1;
+    P.n = n; P.m = m; P.p = p;
+    P.RP = R | 1;
+    P.L = ws_layout(n, m, p);
+    P.wave_doubles = wave_lds_doubles(n, m, P.RP);
+    const int mt = P.L.mp / 64;
+    const size_t shared_bytes = shared ? (size_t)(n + 1 + p) * P.L.mp * 8 : 0;
+    const size_t wave_bytes = (size_t)P.wave_doubles * 8;
+    if (shared_bytes + 16 + wave_bytes > kLdsBytes)
+        return fail(PYMPC_ERR_UNSUPPORTED, "QP %dx%d (p=%d) does not fit the 160 KiB LDS (%zu + %zu B)", n, m, p,
+                    shared_bytes, wave_bytes);
+    int nwaves = (int)((kLdsBytes - shared_bytes - 16) / wave_bytes);
+    // without a staged matrix keep workgroups small so several fit a CU and balance at wave granularity
+    const int max_waves = mt <= 8 ? 8 : 4;   // = solve_max_waves<MT>() (launch bounds of the kernel)
+    const int cap = shared ? max_waves : 4;
+    if (nwaves > cap) nwaves = cap;
+    if ((long long)nwaves > P.B) nwaves = (int)P.B;
+    if (nwaves < 1) nwaves = 1;
+    const size_t lds_bytes = shared_bytes + 16 + wave_bytes * nwaves;
+    long long chunk = nwaves;
+    if (shared) {
+        // amortise the LDS staging of the shared rows over >= 8 problems per wave once the batch fills the chip,
+        // capped so that the dispatcher still has ~8 workgroups per CU to balance with
+        const long long per = (P.B + 2047) / 2048;
+        chunk = per < nwaves ? nwaves : (per > 64LL * nwaves ? 64LL * nwaves : per);
+    }
+    P.chunk = (int)chunk;
+    const long long nwg = (P.B + chunk - 1) / chunk;
+    if (nwg > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    return shared ? launch_solve<true>(mt, P, nwaves, lds_bytes, nwg, st)
+                  : launch_solve<false>(mt, P, nwaves, lds_bytes, nwg, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pympc_hip_abi_version(void) { return 1; }
+
+const char *pympc_hip_last_error(void) { return g_err; }
+
+void pympc_hip_limits(int *n_max, int *m_max)
+{
+    if (n_max) *n_max = kNMax;
+    if (m_max) *m_max = kMMax;
+}
+
+size_t pympc_mpqp_workspace_doubles(int n, int m, int p)
+{
+    if (n < 1 || m < 1 || p < 0 || n > kNMax || m > kMMax) return 0;
+    return ws_layout(n, m, p).total;
+}
+
+int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux, const double *Hxx, const double *fu,
+                       const double *fx, double g, const double *Au, const double *Ax, const double *b, double *ws,
+                       int32_t *ws_status, void *stream)
+{
+    if (int rc = check_shape(n, m, p)) return rc;
+    if (!Huu || !fu || !Au || !b || !ws || !ws_status || (p > 0 && (!Hux || !Hxx || !fx || !Ax)))
+        return fail(PYMPC_ERR_ARG, "pympc_mpqp_prepare: null pointer");
+    PrepParams P;
+    memset(&P, 0, sizeof(P));
+    P.n = n; P.m = m; P.p = p;
+    P.L = ws_layout(n, m, p);
+    P.H = Huu; P.Hux = Hux; P.Hxx = Hxx; P.fu = fu; P.fx = fx; P.gs = nullptr; P.g_host = g;
+    P.A = Au; P.Ax = Ax; P.b = b; P.ws = ws; P.ws_status = ws_status;
+    const size_t lds = (size_t)3 * n * (n + 1) * 8;
+    if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, P);
+    return check_launch("qp_prepare_kernel");
+}
+
+int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *X, int64_t B, double tol, int n_out,
+                           double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
+                           int32_t *iters, void *stream)
+{
+    if (int rc = check_shape(n, m, p)) return rc;
+    if (B < 0 || !ws || !status || (p > 0 && B > 0 && !X)) return fail(PYMPC_ERR_ARG, "pympc_mpqp_solve_batch: bad argument");
+    if (n_out < 0 || n_out > n) return fail(PYMPC_ERR_ARG, "n_out=%d outside [0, %d]", n_out, n);
+    if (B == 0) return 0;
+    SolveParams P;
+    memset(&P, 0, sizeof(P));
+    P.ws = ws; P.ws_stride = 0; P.ws_status = nullptr;
+    P.X = X; P.B = B; P.tol = tol; P.n_out = n_out;
+    P.argmin = n_out > 0 ? argmin : nullptr;
+    P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
+    return solve_common(true, n, m, p, P, (hipStream_t)stream);
+}
+
+size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)
+{
+    if (n < 1 || m < 1 || n > kNMax || m > kMMax || B < 0) return 0;
+    // per-problem prepared workspace + one int32 prepare status per problem (stored after the workspaces)
+    return ws_layout(n, m, 0).total * (size_t)B + ((size_t)B + 1) / 2 + 32;
+}
+
+int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_stride, const double *f, const double *A,
+                         int64_t a_stride, const double *b, double tol, double *ws, double *argmin, double *vmin,
+                         double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream)
+{
+    if (int rc = check_shape(n, m, 0)) return rc;
+    if (B < 0 || !H || !f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: bad argument");
+    if (B == 0) return 0;
+    if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    const WsLayout L = ws_layout(n, m, 0);
+    int32_t *ws_status = reinterpret_cast<int32_t *>(ws + L.total * (size_t)B);
+    PrepParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.n = n; Q.m = m; Q.p = 0; Q.L = L;
+    Q.H = H; Q.h_stride = h_stride;
+    Q.fu = f; Q.fu_stride = n;
+    Q.A = A; Q.a_stride = a_stride;
+    Q.b = b; Q.b_stride = m;
+    Q.g_host = 0.0;
+    Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
+    const size_t lds = (size_t)3 * n * (n + 1) * 8;
+    if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(n * n >= 1024 ? 256 : 64), lds, (hipStream_t)stream, Q);
+    if (int rc = check_launch("qp_prepare_kernel")) return rc;
+    SolveParams P;
+    memset(&P, 0, sizeof(P));
+    P.ws = ws; P.ws_stride = (long long)L.total; P.ws_status = ws_status;
+    P.X = nullptr; P.B = B; P.tol = tol; P.n_out = n;
+    P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
+    return solve_common(false, n, m, 0, P, (hipStream_t)stream);
+}
+
+int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
+                         const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
+                         const double *Vx, const double *V0, const double *X, int64_t B, double tol, int32_t *idx,
+                         double *u, double *V, void *stream)
+{
+    if (nreg < 0 || total_rows < 0 || p < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_point_location: bad shape");
+    if (p > 8) return fail(PYMPC_ERR_UNSUPPORTED, "point location supports up to 8 parameters, got %d", p);
+    if (B == 0) return 0;
+    if (!X || !idx || !V || (nu > 0 && !u) || !row_ptr ||
+        (nreg > 0 && (!A || !b || !Vxx || !Vx || !V0 || (nu > 0 && (!ux || !u0)))))
+        return fail(PYMPC_ERR_ARG, "pympc_point_location: null pointer");
+    PlParams P;
+    memset(&P, 0, sizeof(P));
+    P.nreg = nreg; P.p = p; P.nu = nu; P.total_rows = total_rows;
+    P.A = A; P.b = b; P.row_ptr = row_ptr; P.ux = ux; P.u0 = u0; P.Vxx = Vxx; P.Vx = Vx; P.V0 = V0;
+    P.X = X; P.B = B; P.tol = tol; P.idx = idx; P.u = u; P.V = V;
+    const size_t table_bytes = (size_t)total_rows * (p + 1) * 8;
+    P.table_in_lds = table_bytes <= 150 * 1024;
+    const size_t lds = P.table_in_lds ? table_bytes : 0;
+    const int threads = 256;
+    long long nwg = (B + threads - 1) / threads;
+    const long long cap = 256LL * (lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 8)) * 4;   // grid-stride beyond a few waves of workgroups
+    if (nwg > cap) nwg = cap;
+    hipStream_t st = (hipStream_t)stream;
+#define PYMPC_PL_CASE(PD)                                                                         \
+    case PD: {                                                                                    \
+        if (int rc = allow_lds(point_location_kernel<PD>, lds)) return rc;                        \
+        hipLaunchKernelGGL(point_location_kernel<PD>, dim3((unsigned)nwg), dim3(threads), lds, st, P); \
+        break;                                                                                    \
+    }
+    switch (p) {
+        PYMPC_PL_CASE(1) PYMPC_PL_CASE(2) PYMPC_PL_CASE(3) PYMPC_PL_CASE(4)
+        PYMPC_PL_CASE(5) PYMPC_PL_CASE(6) PYMPC_PL_CASE(7) PYMPC_PL_CASE(8)
+    }
+#undef PYMPC_PL_CASE
+    return check_launch("point_location_kernel");
+}
+
+}  // extern "C"

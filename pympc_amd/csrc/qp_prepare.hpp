@@ -1,0 +1,148 @@
+// One-time factorisation of the constant part of a QP (hoists pnnls.py:210-214 out of the per-state loop):
+//   L = chol(H), L^-1, H^-1 = L^-T L^-1, M = A L^-T, T = A H^-1,
+//   m(x) = (b + T fu) + (T Hux - Ax) x,   u_unc(x) = -H^-1 fu - H^-1 Hux x
+// written in the layout of ws_layout.hpp.  One workgroup per problem (blockIdx.x); the shared-matrix mpQP is the
+// B = 1 case, the per-problem batch (pympc_qp_solve_batch) the p = 0 case.  Same formulation as the reference
+// (explicit L^-1 and H^-1, /root/reference/pympc/optimization/solvers/pnnls.py:211-212) so the numbers agree to
+// rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ws_layout.hpp"
+
+namespace pympc {
+
+struct PrepParams {
+    int n, m, p;
+    WsLayout L;
+    const double *H;   long long h_stride;    // [n x n]
+    const double *Hux; long long hux_stride;  // [n x p] (p may be 0)
+    const double *Hxx; long long hxx_stride;  // [p x p]
+    const double *fu;  long long fu_stride;   // [n]
+    const double *fx;  long long fx_stride;   // [p]
+    const double *gs;  long long g_stride;    // per-problem scalar (device) or null -> g_host
+    double g_host;
+    const double *A;   long long a_stride;    // [m x n]
+    const double *Ax;  long long ax_stride;   // [m x p]
+    const double *b;   long long b_stride;    // [m]
+    double *ws;        long long ws_stride;
+    int32_t *ws_status;
+};
+
+__global__ void qp_prepare_kernel(PrepParams P)
+{
+    extern __shared__ double lds[];
+    const int n = P.n, m = P.m, p = P.p, ld = n + 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long long k = blockIdx.x;
+    const double *H = P.H + k * P.h_stride;
+    const double *Hux = P.Hux ? P.Hux + k * P.hux_stride : nullptr;
+    const double *Hxx = P.Hxx ? P.Hxx + k * P.hxx_stride : nullptr;
+    const double *fu = P.fu + k * P.fu_stride;
+    const double *fx = P.fx ? P.fx + k * P.fx_stride : nullptr;
+    const double *A = P.A + k * P.a_stride;
+    const double *Ax = P.Ax ? P.Ax + k * P.ax_stride : nullptr;
+    const double *b = P.b + k * P.b_stride;
+    double *ws = P.ws + k * P.ws_stride;
+    const WsLayout &L = P.L;
+    const int mp = L.mp;
+
+    double *Ls = lds;             // n x ld, lower Cholesky factor
+    double *Li = Ls + n * ld;     // n x ld, L^-1
+    double *Hi = Li + n * ld;     // n x ld, H^-1
+    __shared__ int notpd;
+    if (tid == 0) notpd = 0;
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e % n;
+        Ls[i * ld + j] = H[i * n + j];
+        Li[i * ld + j] = 0.0;
+    }
+    __syncthreads();
+    // right-looking Cholesky on the lower triangle (numpy.linalg.cholesky, pnnls.py:210)
+    for (int j = 0; j < n; ++j) {
+        const double d = Ls[j * ld + j];
+        if (!(d > 0.0)) {
+            if (tid == 0) notpd = 1;
+            break;   // uniform: every thread read the same d
+        }
+        const double piv = sqrt(d);
+        __syncthreads();
+        for (int i = j + tid; i < n; i += nt) Ls[i * ld + j] = (i == j) ? piv : Ls[i * ld + j] / piv;
+        __syncthreads();
+        const int r = n - j - 1;
+        for (int e = tid; e < r * r; e += nt) {
+            const int i = j + 1 + e / r, c = j + 1 + e % r;
+            if (c <= i) Ls[i * ld + c] -= Ls[i * ld + j] * Ls[c * ld + j];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (P.ws_status && tid == 0) P.ws_status[k] = notpd ? kStatusNotPD : 0;
+    if (notpd) return;
+    // L^-1, one column per thread (pnnls.py:211)
+    for (int c = tid; c < n; c += nt) {
+        Li[c * ld + c] = 1.0 / Ls[c * ld + c];
+        for (int r = c + 1; r < n; ++r) {
+            double s = 0.0;
+            for (int q = c; q < r; ++q) s = fma(Ls[r * ld + q], Li[q * ld + c], s);
+            Li[r * ld + c] = -s / Ls[r * ld + r];
+        }
+    }
+    __syncthreads();
+    // H^-1 = L^-T L^-1 (pnnls.py:212)
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e % n;
+        double s = 0.0;
+        for (int q = (i > j ? i : j); q < n; ++q) s = fma(Li[q * ld + i], Li[q * ld + j], s);
+        Hi[i * ld + j] = s;
+    }
+    __syncthreads();
+    // rows of A: M = A L^-T (pnnls.py:213), T = A H^-1, m0, Gm (pnnls.py:214 split into its affine parts)
+    for (int j = tid; j < mp; j += nt) {
+        if (j < m) {
+            const double *aj = A + (size_t)j * n;
+            for (int i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (int q = 0; q <= i; ++q) s = fma(aj[q], Li[i * ld + q], s);
+                ws[L.Mt + (size_t)i * mp + j] = s;
+            }
+            double mj = b[j];
+            for (int i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (int q = 0; q < n; ++q) s = fma(aj[q], Hi[q * ld + i], s);
+                ws[L.T + (size_t)j * n + i] = s;
+                mj = fma(s, fu[i], mj);
+            }
+            ws[L.m0 + j] = mj;
+            for (int q = 0; q < p; ++q) {
+                double s = -Ax[(size_t)j * p + q];
+                for (int i = 0; i < n; ++i) s = fma(ws[L.T + (size_t)j * n + i], Hux[i * p + q], s);
+                ws[L.Gm + (size_t)q * mp + j] = s;
+            }
+        } else {
+            for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = 0.0;
+            ws[L.m0 + j] = 1.0;
+            for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = 0.0;
+        }
+    }
+    // unconstrained minimiser and copies of the objective blocks
+    for (int i = tid; i < n; i += nt) {
+        double s = 0.0;
+        for (int q = 0; q < n; ++q) s = fma(Hi[i * ld + q], fu[q], s);
+        ws[L.u0 + i] = -s;
+        ws[L.fu + i] = fu[i];
+        for (int c = 0; c < p; ++c) {
+            double t = 0.0;
+            for (int q = 0; q < n; ++q) t = fma(Hi[i * ld + q], Hux[q * p + c], t);
+            ws[L.Ku + i * p + c] = -t;
+            ws[L.Hux + i * p + c] = Hux[i * p + c];
+        }
+    }
+    for (int e = tid; e < n * n; e += nt) ws[L.Huu + e] = H[e];
+    for (int e = tid; e < p * p; e += nt) ws[L.Hxx + e] = Hxx[e];
+    for (int e = tid; e < p; e += nt) ws[L.fx + e] = fx[e];
+    if (tid == 0) ws[L.g] = P.gs ? P.gs[k * P.g_stride] : P.g_host;
+}
+
+}  // namespace pympc

@@ -1,0 +1,66 @@
+// Workspace layout of one prepared QP (shared by host launch code and device kernels).
+//
+// The constant part of pnnls.quadratic_program (/root/reference/pympc/optimization/solvers/pnnls.py:210-214)
+// is factorised once by qp_prepare_kernel and kept in HBM in this layout, all fp64:
+//
+//   Mt  [n  x mp]   Mt[i][j] = M[j][i],  M = Au L^-T            (rows 0..n-1 of the NNLS matrix, negated)
+//   m0  [mp]        m(x) = m0 + Gm' x  = b(x) + Au Huu^-1 f(x)   (last row of the NNLS matrix, negated)
+//   Gm  [p  x mp]
+//   T   [m  x n]    T = Au Huu^-1   (row j = (Huu^-1 a_j)')      (primal recovery, pnnls.py:233)
+//   u0  [n], Ku [n x p]   unconstrained minimiser u_unc(x) = u0 + Ku x = -Huu^-1 f(x)
+//   Huu [n x n], Hux [n x p], fu [n], Hxx [p x p], fx [p], g [1]   (objective, pnnls.py:234 + parametric_programs.py:177)
+//
+// Columns are padded to mp = 64 * MT (MT = columns per lane) so that every lane of a wavefront owns MT
+// columns; pad columns have Mt = 0, Gm = 0, m0 = 1 (their dual w = -1 is never selected).
+// Mt, m0, Gm are contiguous so the shared-matrix kernel stages them into LDS with one linear copy.
+#pragma once
+#include <stddef.h>
+
+namespace pympc {
+
+constexpr int kStatusOptimal = 0;
+constexpr int kStatusInfeasible = 1;
+constexpr int kStatusMaxIter = 3;
+constexpr int kStatusNotPD = 4;
+
+constexpr int kNMax = 63;    // variables: R = n + 1 <= 64 rows, one lane per row
+constexpr int kMTMax = 32;   // columns per lane
+constexpr int kMMax = 64 * kMTMax;
+
+// columns-per-lane bucket for m rows (0 if unsupported)
+__host__ __device__ inline int mt_bucket(int m)
+{
+    const int need = (m + 63) / 64;
+    const int buckets[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    for (int b : buckets)
+        if (need <= b) return b;
+    return 0;
+}
+
+struct WsLayout {
+    int mp;
+    size_t Mt, m0, Gm, T, u0, Ku, Huu, Hux, fu, Hxx, fx, g, total;
+};
+
+__host__ __device__ inline WsLayout ws_layout(int n, int m, int p)
+{
+    WsLayout L;
+    L.mp = 64 * mt_bucket(m);
+    const size_t mp = (size_t)L.mp;
+    L.Mt = 0;
+    L.m0 = L.Mt + (size_t)n * mp;
+    L.Gm = L.m0 + mp;
+    L.T = L.Gm + (size_t)p * mp;
+    L.u0 = L.T + (size_t)m * n;
+    L.Ku = L.u0 + n;
+    L.Huu = L.Ku + (size_t)n * p;
+    L.Hux = L.Huu + (size_t)n * n;
+    L.fu = L.Hux + (size_t)n * p;
+    L.Hxx = L.fu + n;
+    L.fx = L.Hxx + (size_t)p * p;
+    L.g = L.fx + p;
+    L.total = (L.g + 1 + 31) / 32 * 32;   // keep per-problem workspaces 256-byte aligned
+    return L;
+}
+
+}  // namespace pympc

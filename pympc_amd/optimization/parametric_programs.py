@@ -1,0 +1,250 @@
+"""mpQP object and explicit solution, mirroring /root/reference/pympc/optimization/parametric_programs.py.
+
+    MultiParametricQuadraticProgram(H, f, g, A, b)          :10-40
+        .solve(x)                                           :155-179   x 1-D -> sol dict; x 2-D [B x p] -> BatchResult
+        .explicit_solve_given_active_set(active_set)        :42-116
+    CriticalRegion(active_set, u, p, V, polyhedron)         :262-424
+    ExplicitSolution(critical_regions)                      :426-532   get_critical_region / u / p / V, scalar or batched
+
+The numerical work of solve() and of the batched look-ups runs in the HIP kernels (one launch per batch).
+"""
+import numpy as np
+import torch
+
+from .. import _hip
+from .solvers import hip as hip_backend
+
+
+class MultiParametricQuadraticProgram(object):
+    """
+    mpQP in the form
+                      |u|' |Huu  Hux| |u|   |fu|' |u|
+    V(x) := min_u 1/2 |x|  |Hux' Hxx| |x| + |fx|  |x| + g
+             s.t. Au u + Ax x <= b
+    """
+
+    def __init__(self, H, f, g, A, b):
+        self.H = H
+        self.Huu_inv = np.linalg.inv(self.H['uu'])
+        self.f = f
+        self.g = g
+        self.A = A
+        self.b = b
+        self._prepared = None
+
+    # ------------------------------------------------------------------ device side
+    def prepared(self):
+        """Factorise the constant part on the device once (Cholesky of Huu, M, affine maps)."""
+        if self._prepared is None:
+            self._prepared = hip_backend.PreparedMpqp(self.H['uu'], self.H['ux'], self.H['xx'], self.f['u'],
+                                                      self.f['x'], float(self.g), self.A['u'], self.A['x'], self.b)
+        return self._prepared
+
+    def solve(self, x, **kwargs):
+        """
+        Solves the QP at the point x (1-D array: returns the reference's sol dict, parametric_programs.py:155-179)
+        or at every row of x (2-D array / device tensor [B x p]: returns a hip.BatchResult).
+        """
+        if isinstance(x, torch.Tensor):
+            batched = x.dim() == 2
+        else:
+            x = np.asarray(x, dtype=np.float64)
+            batched = x.ndim == 2
+        if batched:
+            return self.prepared().solve_batch(x, **kwargs)
+        x = np.asarray(x, dtype=np.float64).reshape(1, -1)
+        return self.prepared().solve_batch(x).sol(0)
+
+    # ------------------------------------------------------------------ explicit solution (host formulas)
+    def explicit_solve_given_active_set(self, active_set):
+        """
+        KKT solution for a fixed active set (parametric_programs.py:42-116): u(x) = ux x + u0, p(x) = px x + p0,
+        V(x) = .5 x'Vxx x + Vx'x + V0 and the polyhedron where the active set is optimal.  Returns None when the
+        active rows of Au are linearly dependent (LICQ).
+        """
+        from ..geometry.polyhedron import Polyhedron
+        active_set = [int(i) for i in active_set]
+        Au, Ax, b = self.A['u'], self.A['x'], self.b
+        Huu, Hux, Hxx = self.H['uu'], self.H['ux'], self.H['xx']
+        fu, fx = self.f['u'], self.f['x']
+        Hi = self.Huu_inv
+        m = Ax.shape[0]
+        Aua = Au[active_set]
+        if len(active_set) > 0 and np.linalg.matrix_rank(Aua) < Aua.shape[0]:
+            return None
+        inactive = np.setdiff1d(np.arange(m), active_set)
+        # multipliers of the active rows
+        AH = Aua.dot(Hi)
+        S = np.linalg.inv(AH.dot(Aua.T))
+        pax = S.dot(Ax[active_set] - AH.dot(Hux))
+        pa0 = -S.dot(b[active_set] + AH.dot(fu))
+        px = np.zeros(Ax.shape); p0 = np.zeros(m)
+        px[active_set] = pax; p0[active_set] = pa0
+        # primal law
+        ux = -Hi.dot(Hux + Aua.T.dot(pax))
+        u0 = -Hi.dot(fu + Aua.T.dot(pa0))
+        # region: multipliers of active rows >= 0, inactive rows feasible
+        Acr = np.vstack((-pax, Au[inactive].dot(ux) + Ax[inactive]))
+        bcr = np.concatenate((pa0, b[inactive] - Au[inactive].dot(u0)))
+        cr = Polyhedron(Acr, bcr)
+        cr.normalize()
+        # value function
+        Vxx = ux.T.dot(Huu).dot(ux) + 2. * Hux.T.dot(ux) + Hxx
+        Vx = (ux.T.dot(Huu.T) + Hux.T).dot(u0) + ux.T.dot(fu) + fx
+        V0 = .5 * u0.dot(Huu).dot(u0) + fu.dot(u0) + self.g
+        return CriticalRegion(active_set, {'x': ux, '0': u0}, {'x': px, '0': p0}, {'xx': Vxx, 'x': Vx, '0': V0}, cr)
+
+    def explicit_solve_from_samples(self, X, max_regions=None):
+        """
+        Builds an ExplicitSolution from the active sets the batched QP path finds at the sample points X [B x p]
+        (one launch), one CriticalRegion per distinct active set, in order of first appearance.  This is the
+        table-construction route used for the explicit-MPC benchmark: the reference's facet-flipping
+        exploration (parametric_programs.py:181-241) needs thousands of sequential LP/QP calls and is a
+        later row of the scope table.
+        """
+        res = self.solve(np.asarray(X, dtype=np.float64))
+        mask = res.active_mask()
+        feas = res.feasible
+        seen = {}
+        for i in np.where(feas)[0]:
+            key = mask[i].tobytes()
+            if key not in seen:
+                seen[key] = np.where(mask[i])[0]
+                if max_regions is not None and len(seen) >= max_regions:
+                    break
+        crs = []
+        for act in seen.values():
+            cr = self.explicit_solve_given_active_set(list(act))
+            if cr is not None:
+                crs.append(cr)
+        return ExplicitSolution(crs)
+
+
+class CriticalRegion(object):
+    """Region of the parameter space where a fixed active set is optimal (parametric_programs.py:262-424)."""
+
+    def __init__(self, active_set, u, p, V, polyhedron):
+        self.active_set = active_set
+        self._u = u
+        self._p = p
+        self._V = V
+        self.polyhedron = polyhedron
+
+    def contains(self, x):
+        return self.polyhedron.contains(x)
+
+    def minimal_facets(self):
+        return self.polyhedron.minimal_facets()
+
+    def u(self, x):
+        return self._u['x'].dot(x) + self._u['0']
+
+    def p(self, x):
+        return self._p['x'].dot(x) + self._p['0']
+
+    def V(self, x):
+        return .5 * x.dot(self._V['xx']).dot(x) + self._V['x'].dot(x) + self._V['0']
+
+    @property
+    def A(self):
+        return self.polyhedron.A
+
+    @property
+    def b(self):
+        return self.polyhedron.b
+
+
+class ExplicitSolution(object):
+    """
+    Explicit solution of an mpQP: list of critical regions scanned in order, first hit wins
+    (parametric_programs.py:426-532).  Every look-up accepts one point (1-D, reference semantics: None when
+    uncovered) or a batch [B x p] (arrays; index -1 / NaN rows when uncovered); batches run in the HIP
+    point-location kernel with the table resident in LDS.
+    """
+
+    def __init__(self, critical_regions):
+        self.critical_regions = critical_regions
+        self._table = None
+
+    # ------------------------------------------------------------------ device table
+    def table(self, nu=None):
+        """Flattens the regions into the arrays the kernel takes (cached per nu)."""
+        crs = self.critical_regions
+        nu_all = crs[0]._u['x'].shape[0] if crs else 0
+        nu = nu_all if nu is None else nu
+        if self._table is not None and self._table['nu'] == nu:
+            return self._table
+        p = crs[0].polyhedron.A.shape[1]
+        for cr in crs:
+            if cr.polyhedron.C.shape[0] != 0:
+                raise NotImplementedError('critical regions with equalities')
+        row_ptr = np.zeros(len(crs) + 1, np.int32)
+        row_ptr[1:] = np.cumsum([cr.polyhedron.A.shape[0] for cr in crs])
+        t = dict(nu=nu, p=p, nreg=len(crs), total_rows=int(row_ptr[-1]),
+                 A=np.vstack([cr.polyhedron.A for cr in crs]), b=np.concatenate([cr.polyhedron.b for cr in crs]),
+                 row_ptr=row_ptr,
+                 ux=np.array([cr._u['x'][:nu] for cr in crs]).reshape(len(crs), nu, p),
+                 u0=np.array([cr._u['0'][:nu] for cr in crs]).reshape(len(crs), nu),
+                 Vxx=np.array([cr._V['xx'] for cr in crs]), Vx=np.array([cr._V['x'] for cr in crs]),
+                 V0=np.array([cr._V['0'] for cr in crs], dtype=np.float64))
+        t['dev'] = {k: _hip.to_device(t[k]) for k in ('A', 'b', 'ux', 'u0', 'Vxx', 'Vx', 'V0')}
+        t['dev']['row_ptr'] = _hip.to_device(row_ptr, dtype=torch.int32)
+        self._table = t
+        return t
+
+    def locate(self, X, nu=None, tol=1.e-7):
+        """Batched look-up: X [B x p] -> device tensors (idx int32 [B], u [B x nu], V [B]); no synchronisation."""
+        lib = _hip.load_library()
+        t = self.table(nu)
+        X = _hip.to_device(X)
+        if X.dim() != 2 or X.shape[1] != t['p']:
+            raise ValueError('X must be [B x %d]' % t['p'])
+        B = X.shape[0]
+        dev = X.device
+        idx = torch.empty(B, dtype=torch.int32, device=dev)
+        u = torch.empty((B, t['nu']), dtype=torch.float64, device=dev)
+        V = torch.empty(B, dtype=torch.float64, device=dev)
+        d = t['dev']
+        _hip.check(lib.pympc_point_location(t['nreg'], t['total_rows'], t['p'], t['nu'], _hip.ptr(d['A']), _hip.ptr(d['b']),
+                                            _hip.ptr(d['row_ptr']), _hip.ptr(d['ux']), _hip.ptr(d['u0']), _hip.ptr(d['Vxx']),
+                                            _hip.ptr(d['Vx']), _hip.ptr(d['V0']), _hip.ptr(X), B, float(tol),
+                                            _hip.ptr(idx), _hip.ptr(u), _hip.ptr(V), _hip.stream_ptr()))
+        return idx, u, V
+
+    @staticmethod
+    def _is_batch(x):
+        return (isinstance(x, torch.Tensor) and x.dim() == 2) or (not isinstance(x, torch.Tensor) and np.ndim(x) == 2)
+
+    def get_critical_region(self, x):
+        """One point: the CriticalRegion or None (parametric_programs.py:442-463).  Batch: int32 indices, -1 = none."""
+        if self._is_batch(x):
+            return self.locate(x)[0].cpu().numpy()
+        i = int(self.locate(np.asarray(x, dtype=np.float64).reshape(1, -1))[0].item())
+        return None if i < 0 else self.critical_regions[i]
+
+    def u(self, x):
+        if self._is_batch(x):
+            return self.locate(x)[1].cpu().numpy()
+        idx, u, _ = self.locate(np.asarray(x, dtype=np.float64).reshape(1, -1))
+        return None if int(idx.item()) < 0 else u[0].cpu().numpy()
+
+    def p(self, x):
+        """Dual optimiser (parametric_programs.py:488-509): region index from the kernel, affine law on the host."""
+        if self._is_batch(x):
+            idx = self.locate(x)[0].cpu().numpy()
+            X = np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float64)
+            m = self.critical_regions[0]._p['x'].shape[0]
+            out = np.full((len(idx), m), np.nan)
+            for r in np.unique(idx[idx >= 0]):
+                sel = idx == r
+                cr = self.critical_regions[r]
+                out[sel] = X[sel].dot(cr._p['x'].T) + cr._p['0']
+            return out
+        cr = self.get_critical_region(x)
+        return None if cr is None else cr.p(np.asarray(x, dtype=np.float64))
+
+    def V(self, x):
+        if self._is_batch(x):
+            return self.locate(x)[2].cpu().numpy()
+        idx, _, V = self.locate(np.asarray(x, dtype=np.float64).reshape(1, -1))
+        return None if int(idx.item()) < 0 else float(V.item())

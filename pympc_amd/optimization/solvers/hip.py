@@ -1,0 +1,194 @@
+"""`hip` backend: same signatures and `sol` dict as pympc's pnnls backend, computed by the HIP kernels.
+
+Mirrors /root/reference/pympc/optimization/solvers/pnnls.py:
+    quadratic_program(H, f, A, b, C=None, d=None, tol=1e-7)   pnnls.py:149-241
+    linear_program(f, A, b, C=None, d=None, tol=1e-7)          pnnls.py:41-147   (pympc_amd.optimization.solvers.hip_lp)
+plus the batched forms the reference does not have (its callers loop in Python):
+    quadratic_program_batch(H, f, A, b, ...)        B problems of equal shape in one launch
+    PreparedMpqp(...).solve_batch(X)                one mpQP at B parameter values (shared matrices)
+
+Result contract (pnnls.py:128-134): dict with keys min, argmin, active_set, multiplier_inequality,
+multiplier_equality; every value None when infeasible.  Errors: ValueError('missing C or d.'),
+numpy.linalg.LinAlgError (H not positive definite), RuntimeError (NNLS iteration limit).
+"""
+import numpy as np
+import torch
+
+from ... import _hip
+
+TOL = 1.e-7
+
+
+def _empty_sol():
+    return {'min': None, 'argmin': None, 'active_set': None, 'multiplier_inequality': None,
+            'multiplier_equality': None}
+
+
+def _raise_for_status(status):
+    if status == _hip.MAXITER:
+        raise RuntimeError('Maximum number of iterations reached.')
+    if status == _hip.NOT_PD:
+        raise np.linalg.LinAlgError('Matrix is not positive definite')
+
+
+def unpack_active(bits, m):
+    """[B x ceil(m/32)] uint32 words -> [B x m] bool."""
+    b = np.ascontiguousarray(bits).view(np.uint8)
+    return np.unpackbits(b, axis=1, bitorder='little')[:, :m].astype(bool)
+
+
+class BatchResult(object):
+    """Outputs of a batched solve, kept on the device until asked for.
+
+    Tensors (device): status [B] int32, min [B], argmin [B x n_out], multiplier_inequality [B x m] (optional),
+    active_bits [B x ceil(m/32)] int32 (optional), iters [B x 2] int32 (optional).  Infeasible rows hold NaN.
+    """
+
+    def __init__(self, m, n_eq=0, n_ineq=None, **tensors):
+        self.m = m
+        self.n_eq = n_eq
+        self.n_ineq = m if n_ineq is None else n_ineq
+        self.t = tensors
+        self._np = {}
+
+    def numpy(self, key):
+        if key not in self._np:
+            v = self.t.get(key)
+            self._np[key] = None if v is None else v.cpu().numpy()
+        return self._np[key]
+
+    def __len__(self):
+        return int(self.t['status'].shape[0])
+
+    @property
+    def feasible(self):
+        return self.numpy('status') == _hip.OPTIMAL
+
+    def active_mask(self):
+        bits = self.numpy('active_bits')
+        return None if bits is None else unpack_active(bits, self.m)
+
+    def sol(self, i):
+        """Reference-style sol dict of problem i (raises like the scalar API on iteration limit / non-PD)."""
+        st = int(self.numpy('status')[i])
+        _raise_for_status(st)
+        sol = _empty_sol()
+        if st != _hip.OPTIMAL:
+            return sol
+        sol['min'] = float(self.numpy('min')[i])
+        sol['argmin'] = self.numpy('argmin')[i].copy()
+        lam = self.numpy('multiplier_inequality')
+        if lam is not None:
+            lam = lam[i]
+            sol['multiplier_inequality'] = lam[:self.n_ineq].copy()
+            if self.n_eq > 0:
+                sol['multiplier_equality'] = lam[self.n_ineq:self.n_ineq + self.n_eq] - lam[self.n_ineq + self.n_eq:]
+        act = self.numpy('active_bits')
+        if act is not None:
+            row = unpack_active(act[i:i + 1], self.m)[0][:self.n_ineq]
+            sol['active_set'] = [int(j) for j in np.where(row)[0]]
+        return sol
+
+
+def _alloc_outputs(B, n_out, m, dev, want_mult, want_active, want_iters, want_min=True):
+    f64 = dict(dtype=torch.float64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    out = dict(status=torch.empty(B, **i32))
+    out['argmin'] = torch.empty((B, n_out), **f64) if n_out > 0 else None
+    out['min'] = torch.empty(B, **f64) if want_min else None
+    out['multiplier_inequality'] = torch.empty((B, m), **f64) if want_mult else None
+    out['active_bits'] = torch.empty((B, (m + 31) // 32), **i32) if want_active else None
+    out['iters'] = torch.empty((B, 2), **i32) if want_iters else None
+    return out
+
+
+class PreparedMpqp(object):
+    """One mpQP (parametric_programs.py:18-40) factorised once on the device; solve_batch(X) runs the wave kernel.
+
+    Hoists pnnls.py:210-214 (Cholesky, inverses, M) out of the per-state loop.
+    """
+
+    def __init__(self, Huu, Hux, Hxx, fu, fx, g, Au, Ax, b):
+        lib = _hip.load_library()
+        self.dev = _hip.device()
+        self.m, self.n = Au.shape
+        self.p = Ax.shape[1]
+        t = _hip.to_device
+        self._inputs = [t(Huu), t(Hux), t(Hxx), t(fu), t(fx), t(Au), t(Ax), t(b)]
+        nd = lib.pympc_mpqp_workspace_doubles(self.n, self.m, self.p)
+        if nd == 0:
+            nmax, mmax = _hip.limits()
+            raise NotImplementedError('mpQP with n=%d, m=%d is outside the wave kernel limits (n<=%d, m<=%d)'
+                                      % (self.n, self.m, nmax, mmax))
+        self.ws = torch.empty(nd, dtype=torch.float64, device=self.dev)
+        self.ws_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        Huu_, Hux_, Hxx_, fu_, fx_, Au_, Ax_, b_ = self._inputs
+        _hip.check(lib.pympc_mpqp_prepare(self.n, self.m, self.p, _hip.ptr(Huu_), _hip.ptr(Hux_), _hip.ptr(Hxx_),
+                                          _hip.ptr(fu_), _hip.ptr(fx_), float(g), _hip.ptr(Au_), _hip.ptr(Ax_),
+                                          _hip.ptr(b_), _hip.ptr(self.ws), _hip.ptr(self.ws_status), _hip.stream_ptr()))
+        if int(self.ws_status.item()) == _hip.NOT_PD:
+            raise np.linalg.LinAlgError('Matrix is not positive definite')
+
+    def solve_batch(self, X, tol=TOL, n_out=None, want_mult=True, want_active=True, want_iters=False, want_min=True,
+                    out=None):
+        """X: [B x p] (numpy or device tensor).  Returns a BatchResult (device tensors, nothing synchronised)."""
+        lib = _hip.load_library()
+        X = _hip.to_device(X)
+        if X.dim() != 2 or X.shape[1] != self.p:
+            raise ValueError('X must be [B x %d]' % self.p)
+        B = X.shape[0]
+        n_out = self.n if n_out is None else n_out
+        if out is None:
+            out = _alloc_outputs(B, n_out, self.m, self.dev, want_mult, want_active, want_iters, want_min)
+        _hip.check(lib.pympc_mpqp_solve_batch(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(X), B, float(tol), n_out,
+                                              _hip.ptr(out['argmin']), _hip.ptr(out['min']),
+                                              _hip.ptr(out['multiplier_inequality']), _hip.ptr(out['active_bits']),
+                                              _hip.ptr(out['status']), _hip.ptr(out['iters']), _hip.stream_ptr()))
+        return BatchResult(self.m, **out)
+
+
+def quadratic_program_batch(H, f, A, b, tol=TOL, n_eq=0, want_mult=True, want_active=True, want_iters=False):
+    """B strictly convex QPs of equal shape in one launch.
+
+    H: [n x n] (shared) or [B x n x n];  f: [B x n];  A: [m x n] (shared) or [B x m x n];  b: [B x m].
+    Equalities must already be folded as rows (C, -C) (pnnls.py:202-207); n_eq tells BatchResult.sol how to
+    unfold the multipliers.
+    """
+    lib = _hip.load_library()
+    dev = _hip.device()
+    H = _hip.to_device(H); f = _hip.to_device(f); A = _hip.to_device(A); b = _hip.to_device(b)
+    if f.dim() != 2 or b.dim() != 2:
+        raise ValueError('f and b must be [B x n] and [B x m]')
+    B, n = f.shape
+    m = b.shape[1]
+    h_stride = 0 if H.dim() == 2 else n * n
+    a_stride = 0 if A.dim() == 2 else m * n
+    nd = lib.pympc_qp_workspace_doubles(n, m, B)
+    if nd == 0:
+        nmax, mmax = _hip.limits()
+        raise NotImplementedError('QP with n=%d, m=%d is outside the wave kernel limits (n<=%d, m<=%d)'
+                                  % (n, m, nmax, mmax))
+    ws = torch.empty(nd, dtype=torch.float64, device=dev)
+    out = _alloc_outputs(B, n, m, dev, want_mult, want_active, want_iters)
+    _hip.check(lib.pympc_qp_solve_batch(n, m, B, _hip.ptr(H), h_stride, _hip.ptr(f), _hip.ptr(A), a_stride, _hip.ptr(b),
+                                        float(tol), _hip.ptr(ws), _hip.ptr(out['argmin']), _hip.ptr(out['min']),
+                                        _hip.ptr(out['multiplier_inequality']), _hip.ptr(out['active_bits']),
+                                        _hip.ptr(out['status']), _hip.ptr(out['iters']), _hip.stream_ptr()))
+    return BatchResult(m, n_eq=n_eq, n_ineq=m - 2 * n_eq, **out)
+
+
+def quadratic_program(H, f, A, b, C=None, d=None, tol=TOL):
+    """Drop-in for pnnls.quadratic_program (pnnls.py:149-241): one strictly convex QP on the GPU."""
+    if (C is None) != (d is None):
+        raise ValueError('missing C or d.')
+    H = np.asarray(H, dtype=np.float64); f = np.asarray(f, dtype=np.float64)
+    A = np.asarray(A, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    n_eq = 0 if C is None else np.asarray(C).shape[0]
+    if n_eq > 0:   # state equalities as inequalities (pnnls.py:202-207)
+        C = np.asarray(C, dtype=np.float64); d = np.asarray(d, dtype=np.float64)
+        AC = np.vstack((A, C, -C))
+        bd = np.concatenate((b, d, -d))
+    else:
+        AC, bd = A, b
+    res = quadratic_program_batch(H, f[None, :], AC, bd[None, :], tol=tol, n_eq=n_eq)
+    return res.sol(0)

@@ -1,0 +1,126 @@
+"""GPU parity of the shared-matrix batched QP path (pympc_mpqp_prepare / pympc_mpqp_solve_batch through the C ABI)
+against (a) the golden vectors generated from the reference and (b) the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): feasibility decision and active sets bit-exact on certified, non-degenerate
+records; argmin / min / multipliers within 1e-6 relative (fp64).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, unpack_golden_active
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def _prepared(model):
+    from pympc_amd.optimization.solvers.hip import PreparedMpqp
+    return PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model["fx"], float(model["g"]),
+                        model["Au"], model["Ax"], model["b"])
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) if a.size else 0.0
+
+
+def _check_against(res, ref_feas, ref_min, ref_arg, ref_mult, ref_act, trusted, m):
+    st = res.numpy("status")
+    assert set(np.unique(st)).issubset({0, 1})
+    feas = st == 0
+    assert np.array_equal(feas[trusted], ref_feas[trusted]), "feasibility decision differs"
+    sel = trusted & ref_feas & feas
+    act = res.active_mask()
+    assert np.array_equal(act[sel], ref_act[sel]), "active sets differ"
+    assert _rel(res.numpy("argmin")[sel], ref_arg[sel]) < RTOL
+    assert _rel(res.numpy("min")[sel], ref_min[sel]) < RTOL
+    scale = np.maximum(1.0, np.abs(ref_mult[sel]).max(axis=1, keepdims=True))
+    assert np.max(np.abs(res.numpy("multiplier_inequality")[sel] - ref_mult[sel]) / scale) < RTOL
+    # infeasible rows are NaN / empty
+    bad = ~feas
+    assert np.all(np.isnan(res.numpy("min")[bad]))
+    assert not act[bad].any()
+    return int(sel.sum())
+
+
+@pytest.mark.parametrize("model_name,solve_name", [("c1_model", "c1_solves"), ("nb_model", "nb_solves"),
+                                                   ("c2_model", "c2_solves_s03"), ("c2_model", "c2_solves_s10")])
+def test_mpqp_batch_vs_reference_golden(model_name, solve_name):
+    model = golden(model_name)
+    rec = golden(solve_name)
+    m = model["Au"].shape[0]
+    res = _prepared(model).solve_batch(rec["X"], want_iters=True)
+    trusted = rec["oracle_valid"] & ~rec["degenerate"]
+    n = _check_against(res, rec["feasible"], rec["min"], rec["argmin"], rec["multiplier_inequality"],
+                       unpack_golden_active(rec, m), trusted, m)
+    assert n > 0
+    # records the reference's scipy got wrong are judged by their own KKT certificate
+    inv = np.where(~rec["oracle_valid"])[0]
+    for i in inv:
+        sol = res.sol(int(i))
+        if sol["min"] is None:
+            continue
+        x = rec["X"][i]
+        f = model["Hux"].dot(x) + model["fu"]
+        b = model["b"] - model["Ax"].dot(x)
+        u, lam = sol["argmin"], sol["multiplier_inequality"]
+        assert (model["Au"].dot(u) - b).max() < 1e-9 * max(1.0, np.abs(b).max())
+        assert lam.min() >= 0.0
+        assert np.abs(model["Huu"].dot(u) + f + model["Au"].T.dot(lam)).max() < 1e-7 * max(1.0, np.abs(lam).max())
+
+
+def test_notebook_anchor():
+    """examples/linear_mpc.ipynb cell 25: V*(x0 = [.39, .39]) = 100.8236250075..., u* = [-6, -6, -6, -6, -5.05.., -3.68..]."""
+    model = golden("nb_model")
+    rec = golden("nb_solves")
+    res = _prepared(model).solve_batch(rec["nb_x0"][None, :])
+    assert abs(res.numpy("min")[0] - float(rec["nb_V_implicit"])) < 1e-6 * 100.0
+    assert np.allclose(res.numpy("argmin")[0], rec["nb_u_implicit"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("scale,count", [(0.3, 20000), (1.0, 5000)])
+def test_mpqp_batch_vs_oracle_seeded(oracle, scale, count):
+    """Same seeded states through the HIP path and the CPU oracle (C2, larger batch than the golden files)."""
+    model = golden("c2_model")
+    x_max = model["x_max"]
+    X = np.random.RandomState(123).uniform(-scale * x_max, scale * x_max, (count, 4))
+    res = _prepared(model).solve_batch(X)
+    ob = oracle.mpqp_solve_batch(model, X)
+    assert (ob["status"] != 3).all()
+    feas_o = ob["status"] == 0
+    lam = np.where(feas_o[:, None], ob["multiplier_inequality"], 0.0)
+    nz = lam != 0.0
+    edge = (np.abs(lam - 1e-7) < 1e-9 * np.maximum(1.0, np.linalg.norm(lam, axis=1, keepdims=True))) & nz
+    trusted = ~edge.any(axis=1)
+    _check_against(res, feas_o, ob["min"], ob["argmin"], lam, ob["active"], trusted, model["Au"].shape[0])
+
+
+def test_full_size_properties():
+    """BASELINE size (1M states): size-independent properties -- determinism, KKT residuals on a sample, and
+    agreement of the feedback-only launch (n_out = nu, no multipliers) with the full launch."""
+    import torch
+    model = golden("c2_model")
+    x_max = model["x_max"]
+    B = 1000000
+    X = np.random.RandomState(0).uniform(-0.3 * x_max, 0.3 * x_max, (B, 4))
+    prep = _prepared(model)
+    Xd = torch.as_tensor(X).cuda()
+    r1 = prep.solve_batch(Xd, n_out=1, want_mult=False, want_active=True)
+    r2 = prep.solve_batch(Xd, n_out=1, want_mult=False, want_active=True)
+    assert torch.equal(r1.t["status"], r2.t["status"])
+    assert torch.equal(r1.t["active_bits"], r2.t["active_bits"])
+    assert torch.equal(torch.nan_to_num(r1.t["argmin"]), torch.nan_to_num(r2.t["argmin"]))
+    feas = r1.feasible
+    assert 0.85 < feas.mean() < 0.93          # ~89 % feasible at s = 0.3
+    idx = np.random.RandomState(1).choice(B, 2000, replace=False)
+    full = prep.solve_batch(X[idx])
+    assert np.array_equal(full.numpy("status"), r1.numpy("status")[idx])
+    f = full.feasible
+    assert np.allclose(full.numpy("argmin")[f, 0], r1.numpy("argmin")[idx][f, 0], rtol=0, atol=0)
+    U = full.numpy("argmin")[f]; L = full.numpy("multiplier_inequality")[f]; Xs = X[idx][f]
+    bx = model["b"][None, :] - Xs.dot(model["Ax"].T)
+    fx = Xs.dot(model["Hux"].T) + model["fu"][None, :]
+    assert (U.dot(model["Au"].T) - bx).max() < 1e-8 * np.abs(bx).max()
+    assert L.min() >= 0.0
+    stat = U.dot(model["Huu"].T) + fx + L.dot(model["Au"])
+    assert np.abs(stat).max() < 1e-7 * max(1.0, np.abs(L).max())

@@ -1,0 +1,82 @@
+"""The reference's own QP known-answer tests (pympc/test/test_optimization/test_solvers.py:263-345 and
+test_programs.py:71-122), run through the drop-in API of the `hip` backend on the GPU.  Inputs and expected
+values are the data those tests hold; assertions mirror theirs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _qp():
+    from pympc_amd.optimization.programs import quadratic_program
+    return quadratic_program
+
+
+def test_qp_box():
+    # test_solvers.py:265-289
+    sol = _qp()(np.eye(2), np.ones(2), -np.eye(2), -np.ones(2))
+    assert abs(sol['min'] - 3.) < 1e-7
+    np.testing.assert_array_almost_equal(sol['argmin'], np.array([1., 1.]))
+    assert sol['active_set'] == [0, 1]
+    np.testing.assert_array_almost_equal(sol['multiplier_inequality'], np.array([2., 2.]))
+    assert sol['multiplier_equality'] is None
+
+
+def test_qp_equality_and_infeasible():
+    # test_solvers.py:291-319
+    H = np.eye(2); f = np.ones(2); A = -np.eye(2); b = -np.ones(2)
+    C = np.array([[0., 1.]]); d = np.array([2.])
+    sol = _qp()(H, f, A, b, C, d)
+    assert abs(sol['min'] - 5.5) < 1e-7
+    np.testing.assert_array_almost_equal(sol['argmin'], np.array([1., 2.]))
+    assert sol['active_set'] == [0]
+    np.testing.assert_array_almost_equal(sol['multiplier_inequality'], np.array([2., 0.]))
+    np.testing.assert_array_almost_equal(sol['multiplier_equality'], np.array([-3.]))
+    sol = _qp()(H, f, A, b, C, -d)
+    assert all(v is None for v in sol.values())
+
+
+def test_qp_lower_dimensional():
+    # test_solvers.py:321-345
+    sol = _qp()(np.eye(2), np.zeros(2), np.array([[1., 0.], [-1., 0.]]), np.array([1., -1.]))
+    assert abs(sol['min'] - .5) < 1e-7
+    assert abs(sol['argmin'][0] - 1.) < 1e-7
+    assert sol['active_set'] == [1]
+    np.testing.assert_array_almost_equal(sol['multiplier_inequality'], np.array([0., 1.]))
+    assert sol['multiplier_equality'] is None
+
+
+def test_qp_errors():
+    from pympc_amd.optimization.programs import quadratic_program
+    with pytest.raises(ValueError):
+        quadratic_program(np.eye(2), np.ones(2), -np.eye(2), -np.ones(2), C=np.ones((1, 2)))       # pnnls.py:191-192
+    with pytest.raises(ValueError):
+        quadratic_program(np.eye(2), np.ones(2), -np.eye(2), -np.ones(2), solver='nope')            # programs.py:105
+    with pytest.raises(np.linalg.LinAlgError):
+        quadratic_program(np.array([[1., 0.], [0., -1.]]), np.ones(2), -np.eye(2), -np.ones(2))     # pnnls.py:210
+
+
+def test_qp_batch_vs_oracle(oracle):
+    """Per-problem matrices (pympc_qp_solve_batch): random strictly convex QPs, each checked against the oracle."""
+    from pympc_amd.optimization.solvers.hip import quadratic_program_batch
+    rng = np.random.RandomState(5)
+    for (n, m, B) in ((3, 7, 64), (6, 40, 50), (12, 130, 20)):
+        G = rng.randn(B, n, n)
+        H = np.einsum('bij,bkj->bik', G, G) + np.eye(n)[None]
+        f = rng.randn(B, n)
+        A = rng.randn(B, m, n)
+        b = rng.randn(B, m) + 0.5
+        res = quadratic_program_batch(H, f, A, b)
+        for k in range(B):
+            so = oracle.quadratic_program(H[k], f[k], A[k], b[k])
+            sg = res.sol(k)
+            assert (so['min'] is None) == (sg['min'] is None)
+            if so['min'] is None:
+                continue
+            lam = so['multiplier_inequality']
+            nz = lam[lam != 0]
+            if np.any(np.abs(nz - 1e-7) < 1e-9 * max(1., np.linalg.norm(lam))):
+                continue
+            assert sg['active_set'] == so['active_set']
+            assert np.allclose(sg['argmin'], so['argmin'], rtol=1e-6, atol=1e-6 * max(1, np.abs(so['argmin']).max()))
+            assert abs(sg['min'] - so['min']) <= 1e-6 * max(1., abs(so['min']))

@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Headline benchmark: QP solves/sec, cart-pole linear MPC N=20 (config C2 of SURVEY.md section 8), fp64.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (pympc_mpqp_solve_batch: ModelPredictiveController.feedback over a batch) over
+1,000,000 states per GPU that are already resident in HBM; outputs per state are u0, V, status and the active-set
+bit mask (32 B in, 68 B out).  With N > 1 every rank solves its own 1M-state shard (weak scaling) and
+the step ends with the path's one exchange: an RCCL all-gather of (u0, status).  Rank 0 prints ONE JSON line.
+
+The model matrices come from tests/golden/c2_model.npz (condensed by the reference from the cart-pole of
+examples/hybrid_mpc_2.ipynb; the one-time controller set-up is outside the metric).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_VALU_TFLOPS = 78.6     # MI355X fp64 vector peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(n, m, p, outer, inner):
+    """flops of Lawson-Hanson NNLS on the (n+1) x m QP matrix, from the kernel's counters."""
+    kmax = int(outer.max()) if outer.size else 0
+    j = np.arange(1, kmax + 1)
+    jj = np.minimum(j, n + 1)
+    per_outer = 2.0 * (n + 1) * m + 4.0 * np.maximum(n + 2 - jj, 0) * np.maximum(m - jj, 0) + jj.astype(float) ** 2
+    cum = np.concatenate(([0.0], np.cumsum(per_outer)))
+    k = outer.astype(np.int64)
+    jbar = np.minimum(k, n + 1).astype(float)
+    extra = np.maximum(inner.astype(np.int64) - k, 0)
+    F = 2.0 * m * p + cum[k] + 2.0 * (n + 1) * m + 2.0 * n * k + 2.0 * m + extra * (jbar ** 2 + 6.0 * (n + 1))
+    return F
+
+
+def executed_flops(n, m, p, outer, inner):
+    """Flops this kernel actually issues: it sweeps the UNtransformed matrix (2(n+1)m per outer iteration) and
+    updates a small Q / R^-1 pair (~6 R^2) instead of applying each reflector to every column."""
+    R = n + 1
+    k = outer.astype(np.float64)
+    return 2.0 * m * p + k * (2.0 * R * m + 8.0 * R * R) + inner.astype(np.float64) * R * R + 2.0 * n * n + 2.0 * m
+
+
+def cpu_baseline(model, x_max, scale, seconds_target=12.0):
+    """CPU oracle (scalar C port of the reference loop, refactorising per state like pnnls.py:210-213) on a bounded
+    sample of the same workload; 1 core, and a thread fan-out over the box's CPU share for a whole-CPU figure."""
+    from oracle import oracle as O
+    O.build()
+    rng = np.random.RandomState(7)
+    probe = rng.uniform(-scale * x_max, scale * x_max, (2000, 4))
+    t0 = time.perf_counter(); O.mpqp_solve_batch(model, probe, want_mult=False); dt = time.perf_counter() - t0
+    count = int(max(2000, min(200000, seconds_target / (dt / 2000))))
+    X = rng.uniform(-scale * x_max, scale * x_max, (count, 4))
+    t0 = time.perf_counter(); O.mpqp_solve_batch(model, X, want_mult=False); dt = time.perf_counter() - t0
+    one = count / dt
+    out = dict(value=one, unit="QP solves/s", cores=1, kind="port",
+               sample="%d states of the same C2 distribution (s=%.1f), oracle/pnnls_oracle.c oracle_mpqp_solve_batch, %.1f s"
+                      % (count, scale, dt))
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        nth = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        nth = max(1, min(nth, 16))
+        chunks = np.array_split(X, nth)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nth) as ex:
+            list(ex.map(lambda c: O.mpqp_solve_batch(model, c, want_mult=False), chunks))
+        dtm = time.perf_counter() - t0
+        out["all_cores"] = dict(value=count / dtm, cores=nth)
+    except Exception as e:  # pragma: no cover
+        out["all_cores"] = dict(error=str(e))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1000000, help="states per GPU per step")
+    ap.add_argument("--scale", type=float, default=0.3, help="states ~ U(-s x_max, s x_max); 0.3 headline, 1.0 stress")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.stderr.write("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)\n" % args.gpus)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pympc_amd.optimization.solvers.hip import PreparedMpqp, _alloc_outputs
+    model = dict(np.load(os.path.join(ROOT, "tests", "golden", "c2_model.npz")))
+    x_max = model["x_max"]
+    m, n = model["Au"].shape
+    p = model["Ax"].shape[1]
+    nu = model["S_B"].shape[1]
+    prep = PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model["fx"], float(model["g"]),
+                        model["Au"], model["Ax"], model["b"])
+    B = args.batch
+    X = torch.as_tensor(np.random.RandomState(rank).uniform(-args.scale * x_max, args.scale * x_max, (B, p))).to(dev)
+    out = _alloc_outputs(B, nu, m, dev, want_mult=False, want_active=True, want_iters=False)
+    gather = world > 1 and not args.no_gather
+    if gather:
+        g_u = torch.empty((world * B, nu), dtype=torch.float64, device=dev)
+        g_s = torch.empty(world * B, dtype=torch.int32, device=dev)
+
+    def step():
+        prep.solve_batch(X, n_out=nu, out=out)
+        if gather:
+            dist.all_gather_into_tensor(g_u, out["argmin"])
+            dist.all_gather_into_tensor(g_s, out["status"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()                      # HIP events on the stream the kernel is launched on (torch's current stream)
+        prep.solve_batch(X, n_out=nu, out=out)
+        b.record()
+        if gather:
+            dist.all_gather_into_tensor(g_u, out["argmin"])
+            dist.all_gather_into_tensor(g_s, out["status"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline accounting: one extra untimed pass that also writes the iteration counters (deterministic kernel)
+    res = prep.solve_batch(X, n_out=nu, want_mult=False, want_active=False, want_iters=True)
+    torch.cuda.synchronize()
+    iters = res.numpy("iters")
+    status = res.numpy("status")
+    F = algorithmic_flops(n, m, p, iters[:, 0], iters[:, 1])
+    Fx = executed_flops(n, m, p, iters[:, 0], iters[:, 1])
+    alg_bytes = B * (8 * p + 8 * nu + 8 + 4 + 4 * ((m + 31) // 32))
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        achieved = F.sum() / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "QP solves/sec (whole node) for cart-pole MPC N=20",
+            "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: cart-pole linear MPC N=20 (n=%d vars, m=%d rows, p=%d), batched feedback over "
+                                   "%d states per GPU, states ~ U(+-%.1f x_max) seed=rank" % (n, m, p, B, args.scale),
+                       "states_per_gpu": B, "scale": args.scale, "outputs": "u0, V, status, active-set bits",
+                       "exchange": "RCCL all-gather of (u0, status)" if gather else "none",
+                       "feasible_fraction": float((status == 0).mean()),
+                       "mean_outer_iterations": float(iters[:, 0].mean()), "max_outer_iterations": int(iters[:, 0].max())},
+            "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                         "kernel": "qp_solve_kernel<6,true>", "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_launch": float(F.sum()), "executed_flops_per_launch": float(Fx.sum()),
+                         "executed_tflops": Fx.sum() / (kern_ms * 1e-3) / 1e12,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "hbm_algorithmic_gbs": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_gbs": PEAK_HBM_GBS,
+                         "note": "SURVEY 8(d): the NNLS kernels are bound by the fp64 vector ALU (+LDS), not HBM or MFMA"},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(model, x_max, args.scale)
+            line["gpu_over_cpu_1core"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/pympc_hip.h declares; no
+compute call is made (no GPU here)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "pympc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pympc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from pympc_amd import _hip
+    assert _declared() == sorted(_hip.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    from pympc_amd import _hip
+    from pympc_amd.build import build
+    build()
+    lib = _hip.load_library()
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.pympc_hip_abi_version() >= 1
+    nmax, mmax = _hip.limits()
+    assert nmax >= 20 and mmax >= 370
+    assert lib.pympc_mpqp_workspace_doubles(20, 370, 4) > 20 * 370
+    assert lib.pympc_mpqp_workspace_doubles(1000, 370, 4) == 0
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    from pympc_amd import _hip
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.device()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under pympc_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pympc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower().replace("# the cpu oracle", ""), os.path.join(dirpath, f)

@@ -117,3 +117,79 @@ def qp_via_nnls(H, f, A, b, tol=1e-7):
         x = -Hi.dot(f + A.T.dot(lam))
         return dict(status=0, argmin=x, min=.5 * x.dot(H).dot(x) + f.dot(x), mult=lam, active=lam > tol, iters=iters)
     return dict(status=1, iters=iters)
+
+
+# =====================================================================================================
+# LP: numpy model of the HIP LP kernel (pympc_amd/csrc/lp_block.hpp)
+# =====================================================================================================
+def lp_dual_active_set(f, A, b, tol=1e-7, maxit=None):
+    """min f'x s.t. A x <= b  (inequalities only; equalities folded as +-rows by the caller).
+
+    The reference solves the LP's KKT system as one big partially-non-negative least squares problem
+    (pnnls.py:41-147, (1+m+n) x 2m dense).  Its minimiser, when the residual is zero, is a primal-dual optimal pair
+    (x, y); when the LP is infeasible or unbounded the residual is positive and every output is None.  The kernel
+    computes the same pair with an active-set method that only ever factorises n x k matrices (k <= n):
+
+      phase 1  Lawson-Hanson NNLS on the dual-feasibility system  min || A'y + f ||, y >= 0  (n rows, m columns);
+               residual > tol  <=>  no dual feasible point  <=>  LP unbounded or infeasible  -> None
+      phase 2  dual-simplex pivots on the same factorisation Qt A_W' = [R;0], Wi = R^-1:
+               x = Qt'[Wi' b_W; 0] (minimum-norm point of the active face), most violated row e enters;
+               independent of W -> joins with y_e = 0; dependent -> ratio test on d = Wi (Qt a_e)[:k], the blocking
+               row leaves; no blocking row -> primal infeasible -> None.
+    Returns dict(status, argmin, min, mult, active, iters).
+    """
+    f = np.asarray(f, float); A = np.asarray(A, float); b = np.asarray(b, float)
+    m, n = A.shape
+    maxit = 10 * (m + n) + 100 if maxit is None else maxit
+    # ---- phase 1
+    y, r, iters, st = nnls_invqr(A.T, -f)
+    if st:
+        return dict(status=3)
+    scale_f = max(1.0, np.linalg.norm(f))
+    if not (r < tol):
+        return dict(status=1, phase=1, iters=iters)
+    W = [int(j) for j in np.where(y > 0)[0]]
+    yW = [float(y[j]) for j in W]
+
+    def factor(Wl):
+        k = len(Wl)
+        if k == 0:
+            return np.eye(n), np.zeros((0, 0))
+        Q, Rm = np.linalg.qr(A[Wl].T, mode='complete')
+        return Q.T, Rm[:k, :k]
+
+    it = 0
+    anorm = np.linalg.norm(A, axis=1)
+    while True:
+        it += 1
+        if it > maxit:
+            return dict(status=3)
+        k = len(W)
+        Qt, Rm = factor(W)
+        if k:
+            x = Qt[:k].T.dot(np.linalg.solve(Rm.T, b[W]))
+        else:
+            x = np.zeros(n)
+        s = b - A.dot(x)
+        s_rel = s / np.maximum(1.0, np.abs(b))
+        s_rel[W] = np.inf
+        e = int(np.argmin(s_rel))
+        if s_rel[e] >= -1e-9:
+            break
+        q = Qt.dot(A[e])
+        if np.linalg.norm(q[k:]) > 1e-9 * max(anorm[e], 1e-300) and k < n:
+            W.append(e); yW.append(0.0)
+            continue
+        d = np.linalg.solve(Rm, q[:k]) if k else np.zeros(0)
+        ratios = [(yW[i] / d[i], i) for i in range(k) if d[i] > 1e-12 * max(1.0, np.abs(d).max())]
+        if not ratios:
+            return dict(status=1, phase=2, iters=(iters, it))
+        t, l = min(ratios)
+        for i in range(k):
+            yW[i] = max(yW[i] - t * d[i], 0.0)
+        del W[l]; del yW[l]
+        W.append(e); yW.append(t)
+    mult = np.zeros(m)
+    for i, j in enumerate(W):
+        mult[j] = yW[i]
+    return dict(status=0, argmin=x, min=float(f.dot(x)), mult=mult, active=mult > tol, iters=(iters, it), W=W)

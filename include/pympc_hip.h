@@ -93,6 +93,31 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
                          double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream);
 
 /* -------------------------------------------------------------------------------------------------
+ * Batched LP: B problems  min f_k'x  s.t.  A_k x <= b_k  of equal shape (n, m); equalities are folded by the
+ * caller as rows (C, -C) exactly as pnnls.py:101-106 does.
+ * Reference: pympc/optimization/solvers/pnnls.py:41-147 (linear_program) + :5-39 (pnnls) once per problem
+ * (programs.py:9-55); the loops it batches are pympc/geometry/polyhedron.py:435-448 (minimal_facets: one LP per
+ * facet against a SHARED constraint matrix with the i-th right-hand side relaxed by 1, :439-441) and
+ * polyhedron.py:751-756 (Chebyshev centre).
+ * f [B x n]; A [B x m x n] (a_stride = m*n) or [m x n] shared (a_stride 0); b [B x m] (b_stride = m) or [m]
+ * shared (b_stride 0); relax_idx [B] int32 or NULL: b_k[relax_idx[k]] += relax_val (a negative index relaxes
+ * nothing).  ws: pympc_lp_workspace_doubles(...) doubles of device scratch (transposed matrix + row norms).
+ * Outputs (any pointer except status may be NULL): argmin [B x n], vmin [B], mult [B x m] (multiplier_inequality,
+ * pnnls.py:140), active [B x ceil(m/32)] bits of mult > tol (pnnls.py:141), status [B] (PYMPC_OPTIMAL /
+ * PYMPC_INFEASIBLE = infeasible or unbounded, every output None in the reference / PYMPC_MAXITER),
+ * iters [B x 3] (phase-1 outer, phase-1 inner, phase-2 pivots).
+ * ------------------------------------------------------------------------------------------------- */
+size_t pympc_lp_workspace_doubles(int n, int m, int64_t B, int a_shared);
+
+/* Largest LP the workgroup-per-problem kernel accepts. */
+void pympc_lp_limits(int *n_max, int *m_max);
+
+int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double *A, int64_t a_stride, const double *b,
+                         int64_t b_stride, const int32_t *relax_idx, double relax_val, double tol, double *ws,
+                         double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status, int32_t *iters,
+                         void *stream);
+
+/* -------------------------------------------------------------------------------------------------
  * Explicit-MPC point location + affine law: first critical region (list order) containing each point.
  * Reference: pympc/optimization/parametric_programs.py:442-463 (get_critical_region), :465-532 (u, V),
  * :349-400 (CriticalRegion.u / V), pympc/geometry/polyhedron.py:578-604 (contains, tol 1e-7).

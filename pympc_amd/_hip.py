@@ -29,6 +29,10 @@ SIGNATURES = {
     "pympc_qp_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i64]),
     "pympc_qp_solve_batch": (_i, [_i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp]),
+    "pympc_lp_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i64, _i]),
+    "pympc_lp_limits": (None, [ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "pympc_lp_solve_batch": (_i, [_i, _i, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp]),
     "pympc_point_location": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp,
                                   _vp]),
 }
@@ -95,4 +99,11 @@ def limits():
     n = _i(0)
     m = _i(0)
     load_library().pympc_hip_limits(ctypes.byref(n), ctypes.byref(m))
+    return n.value, m.value
+
+
+def lp_limits():
+    n = _i(0)
+    m = _i(0)
+    load_library().pympc_lp_limits(ctypes.byref(n), ctypes.byref(m))
     return n.value, m.value

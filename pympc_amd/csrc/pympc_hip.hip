@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../include/pympc_hip.h"
+#include "lp_block.hpp"
 #include "point_location.hpp"
 #include "qp_prepare.hpp"
 #include "qp_wave.hpp"
@@ -210,6 +211,63 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
     P.X = nullptr; P.B = B; P.tol = tol; P.n_out = n;
     P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
     return solve_common(false, n, m, 0, P, (hipStream_t)stream);
+}
+
+size_t pympc_lp_workspace_doubles(int n, int m, int64_t B, int a_shared)
+{
+    if (n < 1 || m < 1 || n > kLpNMax || m > kLpMMax || B < 0) return 0;
+    return (size_t)(n + 1) * m * (a_shared ? 1 : (size_t)B) + 32;
+}
+
+void pympc_lp_limits(int *n_max, int *m_max)
+{
+    if (n_max) *n_max = kLpNMax;
+    if (m_max) *m_max = kLpMMax;
+}
+
+int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double *A, int64_t a_stride, const double *b,
+                         int64_t b_stride, const int32_t *relax_idx, double relax_val, double tol, double *ws,
+                         double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status, int32_t *iters,
+                         void *stream)
+{
+    if (n < 1 || m < 1 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_lp_solve_batch: bad shape n=%d m=%d", n, m);
+    if (n > kLpNMax) return fail(PYMPC_ERR_UNSUPPORTED, "n=%d exceeds the LP kernel's limit of %d variables", n, kLpNMax);
+    if (m > kLpMMax) return fail(PYMPC_ERR_UNSUPPORTED, "m=%d exceeds the LP kernel's limit of %d rows", m, kLpMMax);
+    if (!f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_lp_solve_batch: null pointer");
+    if (a_stride != 0 && a_stride < (int64_t)m * n) return fail(PYMPC_ERR_ARG, "a_stride %lld < m*n", (long long)a_stride);
+    if (b_stride != 0 && b_stride < m) return fail(PYMPC_ERR_ARG, "b_stride %lld < m", (long long)b_stride);
+    if (B == 0) return 0;
+    if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nA = a_stride == 0 ? 1 : B;
+    if (nA > 65535) return fail(PYMPC_ERR_UNSUPPORTED, "more than 65535 distinct constraint matrices in one call");
+    LpPrepParams Q;
+    Q.n = n; Q.m = m; Q.A = A; Q.a_stride = a_stride; Q.ws = ws; Q.ws_stride = (long long)(n + 1) * m;
+    const int pt = 256;
+    int pgx = (m + pt - 1) / pt;
+    if (pgx > 1024) pgx = 1024;
+    hipLaunchKernelGGL(lp_prepare_kernel, dim3(pgx, (unsigned)nA), dim3(pt), 0, st, Q);
+    if (int rc = check_launch("lp_prepare_kernel")) return rc;
+
+    LpParams P;
+    memset(&P, 0, sizeof(P));
+    P.n = n; P.m = m; P.RP = n | 1;
+    P.At = ws; P.at_stride = a_stride == 0 ? 0 : (long long)(n + 1) * m;
+    P.f = f; P.f_stride = n;
+    P.b = b; P.b_stride = b_stride;
+    P.relax_idx = relax_idx; P.relax_val = relax_val;
+    P.B = B; P.tol = tol;
+    P.maxit = 10 * (m + n) + 100;
+    P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
+    // rows per thread ~8-20: one wavefront for small LPs, up to 8 for the 10k-facet polytopes
+    int threads = ((m / 16 + 63) / 64) * 64;
+    if (threads < 64) threads = 64;
+    if (threads > 512) threads = 512;
+    const size_t lds_bytes = lp_lds_doubles(n, m, P.RP, threads / 64) * 8;
+    if (lds_bytes > kLdsBytes) return fail(PYMPC_ERR_UNSUPPORTED, "LP %dx%d does not fit the 160 KiB LDS", n, m);
+    if (int rc = allow_lds(lp_solve_kernel, lds_bytes)) return rc;
+    hipLaunchKernelGGL(lp_solve_kernel, dim3((unsigned)B), dim3(threads), lds_bytes, st, P);
+    return check_launch("lp_solve_kernel");
 }
 
 int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,

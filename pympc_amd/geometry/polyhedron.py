@@ -1,0 +1,367 @@
+"""H-representation polyhedra {x | A x <= b, C x = d}: the part of /root/reference/pympc/geometry/polyhedron.py that sits
+on the pnnls hot path, with the per-facet LP loops issued as batches to the HIP LP kernel.
+
+Same names, arguments and error behaviour as the reference for
+    Polyhedron(A, b, C=None, d=None)                         polyhedron.py:20-61
+    add_inequality / add_equality / add_*_bound(s)           :63-199      (host-side builders)
+    from_lower_bound / from_upper_bound / from_bounds        :239-336
+    normalize(tol)                                           :379-401
+    minimal_facets(tol) / remove_redundant_inequalities()    :403-466     one LP per facet -> batched
+    _remove_equalities()                                     :468-503
+    empty                                                    :505-526     one QP
+    bounded                                                  :528-576     one LP
+    contains(x, tol)                                         :578-604     x 1-D (bool) or [B x n] (bool array, HIP)
+    is_included_in(P2, tol)                                  :606-641     one LP per facet of P2 -> batched
+    intersection / cartesian_product                         :643-685
+    radius / center / _chebyshev()                           :687-768     one LP
+Vertex enumeration, projection and plotting (qhull / matplotlib glue) are outside the hot path.
+"""
+from copy import copy
+
+import numpy as np
+
+from ..optimization.programs import linear_program, quadratic_program
+from ..optimization.solvers import hip_lp
+
+
+def nullspace_basis(A):
+    """Orthonormal basis of ker(A) from the SVD (geometry/utils.py:4-26)."""
+    V = np.linalg.svd(A)[2].T
+    return V[:, np.linalg.matrix_rank(A):]
+
+
+def block_diag(*blocks):
+    rows = sum(B.shape[0] for B in blocks)
+    cols = sum(B.shape[1] for B in blocks)
+    out = np.zeros((rows, cols))
+    r = c = 0
+    for B in blocks:
+        out[r:r + B.shape[0], c:c + B.shape[1]] = B
+        r += B.shape[0]
+        c += B.shape[1]
+    return out
+
+
+class Polyhedron(object):
+    """Polyhedron in the form {x in R^n | A x <= b, C x = d}."""
+
+    def __init__(self, A, b, C=None, d=None):
+        if len(b.shape) > 1:
+            raise ValueError('b must be a one dimensional array.')
+        self._same_number_rows(A, b)
+        self.A = A
+        self.b = b
+        if (C is None) != (d is None):
+            raise ValueError('missing C or d.')
+        if C is None:
+            self.C = np.zeros((0, A.shape[1]))
+            self.d = np.zeros(0)
+        else:
+            if len(d.shape) > 1:
+                raise ValueError('b must be a one dimensional array.')
+            self._same_number_rows(C, d)
+            self.C = C
+            self.d = d
+        self._delete_attributes()
+
+    # ------------------------------------------------------------------ builders (host side)
+    def _delete_attributes(self):
+        self._empty = None
+        self._bounded = None
+        self._radius = None
+        self._center = None
+        self._vertices = None
+
+    @staticmethod
+    def _same_number_rows(E, f):
+        if E.shape[0] != f.size:
+            raise ValueError("incoherent size of the inputs.")
+
+    def _selection_matrix(self, indices=None):
+        """S such that S x = x[indices] (rows of the identity, in increasing index order)."""
+        n = self.A.shape[1]
+        if indices is None:
+            return np.eye(n)
+        keep = [i for i in range(n) if i in indices]
+        return np.eye(n)[keep]
+
+    def add_inequality(self, A, b, indices=None):
+        self._same_number_rows(A, b)
+        self._delete_attributes()
+        S = self._selection_matrix(indices)
+        self.A = np.vstack((self.A, A.dot(S)))
+        self.b = np.concatenate((self.b, b))
+
+    def add_equality(self, C, d, indices=None):
+        self._same_number_rows(C, d)
+        self._delete_attributes()
+        S = self._selection_matrix(indices)
+        self.C = np.vstack((self.C, C.dot(S)))
+        self.d = np.concatenate((self.d, d))
+
+    def add_lower_bound(self, x_min, indices=None):
+        if isinstance(x_min, float):
+            x_min = np.array([x_min])
+        self.add_inequality(-self._selection_matrix(indices), -x_min)
+
+    def add_upper_bound(self, x_max, indices=None):
+        if isinstance(x_max, float):
+            x_max = np.array([x_max])
+        self.add_inequality(self._selection_matrix(indices), x_max)
+
+    def add_bounds(self, x_min, x_max, indices=None):
+        self.add_lower_bound(x_min, indices)
+        self.add_upper_bound(x_max, indices)
+
+    @staticmethod
+    def _blank(size, indices, n):
+        if indices is not None and n is None:
+            raise ValueError("specify the length of x to instantiate the polyhedron.")
+        n = size if n is None else n
+        return Polyhedron(np.zeros((0, n)), np.zeros(0))
+
+    @staticmethod
+    def from_lower_bound(x_min, indices=None, n=None):
+        p = Polyhedron._blank(x_min.size, indices, n)
+        p.add_lower_bound(x_min, indices)
+        return p
+
+    @staticmethod
+    def from_upper_bound(x_max, indices=None, n=None):
+        p = Polyhedron._blank(x_max.size, indices, n)
+        p.add_upper_bound(x_max, indices)
+        return p
+
+    @staticmethod
+    def from_bounds(x_min, x_max, indices=None, n=None):
+        if indices is not None and n is None:
+            raise ValueError("specify the length of x to instantiate the polyhedron.")
+        if x_min.size != x_max.size:
+            raise ValueError("bounds must have the same size.")
+        p = Polyhedron._blank(x_min.size, indices, n)
+        p.add_bounds(x_min, x_max, indices)
+        return p
+
+    def normalize(self, tol=1.e-7):
+        """Divides every row of [A b] and [C d] by the norm of its left-hand side (rows with norm <= tol untouched)."""
+        for M, v in ((self.A, self.b), (self.C, self.d)):
+            for i in range(M.shape[0]):
+                r = np.linalg.norm(M[i])
+                if r > tol:
+                    M[i] = M[i] / r
+                    v[i] = v[i] / r
+
+    def intersection(self, P2):
+        P3 = copy(P2)
+        P3.add_inequality(self.A, self.b)
+        P3.add_equality(self.C, self.d)
+        return P3
+
+    def cartesian_product(self, P2):
+        return Polyhedron(block_diag(self.A, P2.A), np.concatenate((self.b, P2.b)),
+                          block_diag(self.C, P2.C), np.concatenate((self.d, P2.d)))
+
+    # ------------------------------------------------------------------ equality elimination
+    def _remove_equalities(self):
+        """x = N n + R r with N = null(C), R = null(N'), r = (C R)^-1 d  ->  {n | E n <= f} (polyhedron.py:468-503)."""
+        N = nullspace_basis(self.C)
+        if N.shape[1] == 0:
+            raise ValueError('equality constraints C x = d do not have a nullspace.')
+        if N.shape[1] != self.C.shape[1] - self.C.shape[0]:
+            raise ValueError('equality constraints C x = d are linearly dependent.')
+        R = nullspace_basis(N.T)
+        E = self.A.dot(N)
+        r = np.linalg.inv(self.C.dot(R)).dot(self.d)
+        f = self.b - self.A.dot(R.dot(r))
+        return E, f, N, R
+
+    # ------------------------------------------------------------------ redundancy removal (batched LPs)
+    def minimal_facets(self, tol=1.e-7):
+        """
+        Indices of a minimal set of inequalities (None if the polyhedron is empty), polyhedron.py:403-450.
+
+        The reference tests facet i against the set from which the facets found redundant before i have already been
+        removed (one LP at a time, :435-448).  The same list is obtained from two batched launches plus a short
+        sequential tail:
+          1. every facet against the FULL set (b_i relaxed by 1): a facet that is not redundant here is not redundant
+             against any subset, so it is kept for sure; the others are candidates;
+          2. every candidate against the surely-kept facets only: redundant there means redundant against any
+             superset, so it is removed for sure;
+          3. the candidates that survive 2 (duplicated or touching facets) are re-tested one by one, in index order,
+             against exactly the set the reference would hold at that point.
+        """
+        if self.empty:
+            return None
+        if self.C.shape[0] != 0:
+            E, f, _, _ = self._remove_equalities()
+        else:
+            E, f = self.A, self.b
+        m = E.shape[0]
+        if m == 0:
+            return []
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        f = np.ascontiguousarray(f, dtype=np.float64)
+
+        def values(res, idx):
+            st = res.numpy('status')
+            mn = res.numpy('min')
+            if np.any(st == 3):
+                raise RuntimeError('Maximum number of iterations reached.')
+            return np.where(st == 0, -mn - f[idx], np.inf)
+
+        # 1. all facets against the full relaxed set
+        res = hip_lp.linear_program_batch(-E, E, f, relax_idx=np.arange(m, dtype=np.int32), relax_val=1.,
+                                          want_argmin=False, want_mult=False, want_active=False)
+        v1 = values(res, np.arange(m))
+        cand = np.where(v1 < tol)[0]
+        sure = np.where(~(v1 < tol))[0]
+        removed = np.zeros(m, bool)
+        undecided = cand
+        # 2. candidates against the surely kept facets
+        if cand.size > 0 and sure.size > 0:
+            res = hip_lp.linear_program_batch(-E[cand], E[sure], f[sure], want_argmin=False, want_mult=False,
+                                              want_active=False)
+            v2 = values(res, cand)
+            gone = v2 < tol
+            undecided = cand[~gone]
+        # 3. the rest in index order, against the reference's current set
+        pending_sure = set(cand.tolist()) - set(undecided.tolist())   # removed when their turn comes
+        for i in undecided:
+            removed[[j for j in pending_sure if j < i]] = True
+            cur = np.where(~removed)[0]
+            rel = f.copy()
+            rel[i] += 1.
+            sol = linear_program(-E[i], E[cur], rel[cur])
+            if - sol['min'] - f[i] < tol:
+                removed[i] = True
+        removed[list(pending_sure)] = True
+        return [int(i) for i in np.where(~removed)[0]]
+
+    def remove_redundant_inequalities(self):
+        """Removes the redundant facets of the polyhedron, it modifies the attributes A and b (polyhedron.py:452-466)."""
+        minimal_facets = self.minimal_facets()
+        if minimal_facets is None:
+            raise ValueError('empty polyhedron, cannot remove redundant inequalities.')
+        self.A = self.A[minimal_facets]
+        self.b = self.b[minimal_facets]
+
+    # ------------------------------------------------------------------ emptiness / boundedness / membership
+    @property
+    def empty(self):
+        """True iff the minimum-norm QP over the polyhedron is infeasible (polyhedron.py:505-526)."""
+        if self._empty is not None:
+            return self._empty
+        n = self.A.shape[1]
+        m_qp = self.A.shape[0] + 2 * self.C.shape[0]
+        from .. import _hip
+        n_max, m_max = _hip.limits()
+        if m_qp == 0:
+            self._empty = False
+        elif n <= n_max and m_qp <= m_max:
+            sol = quadratic_program(np.eye(n), np.zeros(n), self.A, self.b, self.C, self.d)
+            self._empty = sol['min'] is None
+        else:
+            # more rows than the wave-per-QP kernel holds: same decision from the feasibility LP min 0'x
+            sol = linear_program(np.zeros(n), self.A, self.b, self.C, self.d)
+            self._empty = sol['min'] is None
+        return self._empty
+
+    @property
+    def bounded(self):
+        """Stiemke's alternative: bounded iff ker(A) = 0 and some y >= 1 has A'y = 0 (polyhedron.py:528-576)."""
+        if self._bounded is not None:
+            return self._bounded
+        if self.empty:
+            return True
+        A = np.vstack((self.A, self.C, -self.C))
+        if nullspace_basis(A).shape[1] > 0:
+            return False
+        n, m = A.shape
+        sol = linear_program(np.ones(n), -np.eye(n), -np.ones(n), A.T, np.zeros(m))
+        self._bounded = sol['min'] is not None
+        return self._bounded
+
+    def contains(self, x, tol=1.e-7):
+        """
+        max(A x - b) <= tol and |max(C x - d)| <= tol (polyhedron.py:578-604).  x 1-D: bool.  x [B x n] (array or device
+        tensor): bool array, evaluated by the HIP point-location kernel with this polyhedron as the only region.
+        """
+        import torch
+        if isinstance(x, torch.Tensor) or np.ndim(x) == 2:
+            return self._contains_batch(x, tol)
+        in_ineq = np.max(self.A.dot(x) - self.b) <= tol
+        in_eq = True
+        if self.C.shape[0] > 0:
+            in_eq = np.abs(np.max(self.C.dot(x) - self.d)) <= tol
+        return bool(in_ineq and in_eq)
+
+    def _contains_batch(self, X, tol):
+        import torch
+        from .. import _hip
+        lib = _hip.load_library()
+        if self.C.shape[0] > 0:
+            raise NotImplementedError('batched contains with equalities')
+        X = _hip.to_device(X)
+        B, p = X.shape
+        m = self.A.shape[0]
+        A = _hip.to_device(self.A); b = _hip.to_device(self.b)
+        row_ptr = _hip.to_device(np.array([0, m], np.int32), dtype=torch.int32)
+        z = torch.zeros(max(p * p, 1), dtype=torch.float64, device=X.device)
+        idx = torch.empty(B, dtype=torch.int32, device=X.device)
+        V = torch.empty(B, dtype=torch.float64, device=X.device)
+        _hip.check(lib.pympc_point_location(1, m, p, 0, _hip.ptr(A), _hip.ptr(b), _hip.ptr(row_ptr), None, None,
+                                            _hip.ptr(z), _hip.ptr(z), _hip.ptr(z), _hip.ptr(X), B, float(tol),
+                                            _hip.ptr(idx), None, _hip.ptr(V), _hip.stream_ptr()))
+        return (idx == 0).cpu().numpy()
+
+    def is_included_in(self, P2, tol=1.e-7):
+        """P subset of P2?  One LP per facet of P2 (polyhedron.py:606-641), issued as one batch."""
+        A1 = np.vstack((self.A, self.C, -self.C))
+        b1 = np.concatenate((self.b, self.d, -self.d))
+        A2 = np.vstack((P2.A, P2.C, -P2.C))
+        b2 = np.concatenate((P2.b, P2.d, -P2.d))
+        if A2.shape[0] == 0:
+            return True
+        res = hip_lp.linear_program_batch(-A2, A1, b1, want_argmin=False, want_mult=False, want_active=False)
+        st = res.numpy('status')
+        if np.any(st == 3):
+            raise RuntimeError('Maximum number of iterations reached.')
+        if np.any(st != 0):
+            # the reference evaluates -None here (TypeError); an unbounded direction certainly leaves P2
+            return False
+        penetration = - res.numpy('min') - b2
+        return bool(not np.any(penetration > tol))
+
+    # ------------------------------------------------------------------ Chebyshev centre
+    @property
+    def radius(self):
+        if self._radius is not None:
+            return self._radius
+        self._radius, self._center = self._chebyshev()
+        return self._radius
+
+    @property
+    def center(self):
+        if self._center is not None:
+            return self._center
+        self._radius, self._center = self._chebyshev()
+        return self._center
+
+    def _chebyshev(self):
+        """LP  min e  s.t.  F z - ||F_i|| e <= g  (polyhedron.py:727-768); radius = -min, centre = z."""
+        if self.C.shape[0] > 0:
+            A, b, N, R = self._remove_equalities()
+        else:
+            A, b = self.A, self.b
+        f_lp = np.concatenate((np.zeros(A.shape[1]), np.ones(1)))
+        A_lp = np.hstack((A, -np.linalg.norm(A, axis=1).reshape(-1, 1)))
+        sol = linear_program(f_lp, A_lp, b)
+        radius = sol['min']
+        center = sol['argmin']
+        if radius is not None:
+            radius = -radius
+            center = center[:-1]
+            if self.C.shape[0] > 0:
+                r = np.linalg.inv(self.C.dot(R)).dot(self.d)
+                center = np.hstack((N, R)).dot(np.concatenate((center, r)))
+        return radius, center

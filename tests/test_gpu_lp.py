@@ -1,0 +1,146 @@
+"""GPU parity of the LP path (pympc_lp_solve_batch through the drop-in API).
+
+  * the reference's own LP known-answer tests (pympc/test/test_optimization/test_solvers.py:12-256), same data and
+    assertions as tests/test_oracle.py applies to the oracle;
+  * golden vectors produced by the reference in the build container (tests/golden/lp_polytopes.npz);
+  * seeded random LPs (bounded, infeasible, unbounded, degenerate, duplicated / zero rows) against the CPU oracle's
+    restatement of pnnls.linear_program.
+Tolerances: solvability and active sets exact; min / argmin / multipliers within 1e-6 (relative to max(1, |.|)).
+Degenerate LPs (non-unique primal or dual optimum) are compared through the optimal value only, as SURVEY 8(c) says.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from test_oracle import _lp_kats
+
+pytestmark = pytest.mark.gpu
+
+
+def _lp():
+    from pympc_amd.optimization.programs import linear_program
+    return linear_program
+
+
+def test_reference_lp_kats():
+    _lp_kats(_lp())
+
+
+def test_lp_errors():
+    lp = _lp()
+    with pytest.raises(ValueError):
+        lp(np.ones(2), -np.eye(2), np.zeros(2), C=np.ones((1, 2)))                 # pnnls.py:90-91
+    with pytest.raises(ValueError):
+        lp(np.ones(2), -np.eye(2), np.zeros(2), solver='nope')                     # programs.py:55
+
+
+def test_programs_lp_kats():
+    # test_programs.py:14-64 (dispatch layer): same two LPs through solver='pnnls' alias and the default
+    f = np.ones(2); A = np.array([[1., 0.], [-1., 0.], [0., 1.], [0., -1.]]); b = np.array([5., 5., 1., 1.])
+    for kw in ({}, {'solver': 'pnnls'}, {'solver': 'hip'}):
+        sol = _lp()(f, A, b, **kw)
+        assert abs(sol['min'] + 6.) < 1e-7
+        np.testing.assert_array_almost_equal(sol['argmin'], [-5., -1.])
+        assert sol['active_set'] == [1, 3]
+
+
+def test_generic_lps_vs_reference_golden():
+    g = golden("lp_polytopes")
+    from pympc_amd.optimization.solvers.hip_lp import linear_program_batch
+    res = linear_program_batch(g["lp_f"], g["lp_A"], g["lp_b"])
+    valid = g["lp_valid"].astype(bool)
+    solv = g["lp_solvable"].astype(bool)
+    assert np.array_equal(res.feasible[valid], solv[valid])
+    sel = valid & solv
+    assert np.allclose(res.numpy('min')[sel], g["lp_min"][sel], rtol=1e-6, atol=1e-6)
+    assert np.allclose(res.numpy('argmin')[sel], g["lp_argmin"][sel], rtol=1e-6, atol=1e-6)
+    assert np.allclose(res.numpy('multiplier_inequality')[sel], g["lp_mult"][sel], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(res.active_mask()[sel], g["lp_mult"][sel] > 1e-7)
+    assert np.all(np.isnan(res.numpy('min')[~res.feasible]))
+
+
+@pytest.mark.parametrize("m", [30, 60, 100])
+def test_polytope_vs_reference_golden(m):
+    """Polyhedron.minimal_facets / remove_redundant_inequalities / radius / center (config C3 recipe, small m)."""
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    g = golden("lp_polytopes")
+    A = g["m%d_A" % m]; b = g["m%d_b" % m]
+    P = Polyhedron(A.copy(), b.copy())
+    mf = P.minimal_facets()
+    assert mf == list(g["m%d_minimal_facets" % m])                       # bit-exact index list
+    assert abs(P.radius - float(g["m%d_radius" % m])) < 1e-6
+    assert np.allclose(P.center, g["m%d_center" % m], rtol=1e-6, atol=1e-6)
+    P.remove_redundant_inequalities()
+    assert np.array_equal(P.A, A[mf]) and np.array_equal(P.b, b[mf])
+    # idempotence: a minimal representation has no redundant facet left
+    assert Polyhedron(P.A.copy(), P.b.copy()).minimal_facets() == list(range(len(mf)))
+    # Chebyshev multipliers and the per-facet LP values of polyhedron.py:447 against the full set (step 1)
+    from pympc_amd.optimization.solvers.hip_lp import linear_program_batch
+    Alp = np.hstack((A, -np.linalg.norm(A, axis=1)[:, None]))
+    res = linear_program_batch(np.concatenate((np.zeros(6), [1.]))[None, :], Alp, b)
+    assert np.allclose(res.numpy('multiplier_inequality')[0], g["m%d_cheb_mult" % m], atol=1e-6)
+
+
+def test_random_lps_vs_oracle(oracle):
+    rng = np.random.RandomState(5)
+    lp = _lp()
+    n_solv = 0
+    for t in range(200):
+        n = rng.randint(1, 7); m = rng.randint(1, 25)
+        kind = t % 5
+        A = rng.randn(m, n)
+        if kind == 0:
+            b = 1 + rng.rand(m)
+        elif kind == 1:
+            b = rng.randn(m)
+        elif kind == 2:
+            A = np.round(A); b = np.round(rng.randn(m) * 2)               # integer data: degenerate vertices
+        elif kind == 3:
+            e = max(1, m // 3)
+            A = np.vstack((A, A[:e])); b = np.concatenate((1 + rng.rand(m), 1 + rng.rand(e)))   # duplicated rows
+        else:
+            A[rng.randint(m)] = 0; b = rng.rand(m) - .1                    # a zero row, sometimes infeasible
+        f = rng.randn(n) if kind != 2 else np.round(rng.randn(n) * 2)
+        ref = oracle.linear_program(f, A, b)
+        sol = lp(f, A, b)
+        assert (sol['min'] is None) == (ref['min'] is None), (t, kind)
+        if ref['min'] is None:
+            assert all(v is None for v in sol.values())
+            continue
+        n_solv += 1
+        assert abs(sol['min'] - ref['min']) < 1e-6 * max(1., abs(ref['min'])), (t, kind)
+        # primal feasibility, dual feasibility and complementarity of what the kernel returned
+        x, y = sol['argmin'], sol['multiplier_inequality']
+        assert (A.dot(x) - b).max() < 1e-7 * max(1., np.abs(b).max())
+        assert y.min() >= 0. and np.abs(A.T.dot(y) + f).max() < 1e-7 * max(1., np.abs(y).max())
+        if kind in (0, 1):   # generic data: unique primal-dual pair, active set bit-exact
+            assert np.allclose(x, ref['argmin'], rtol=1e-6, atol=1e-6), (t, kind)
+            assert np.allclose(y, ref['multiplier_inequality'], rtol=1e-6, atol=1e-6), (t, kind)
+            assert sol['active_set'] == ref['active_set'], (t, kind)
+    assert n_solv > 50
+
+
+def test_lp_batch_shared_matrix_relaxation(oracle):
+    """The minimal_facets batch form: shared A, shared b, per-problem relaxed row (polyhedron.py:439-441)."""
+    from pympc_amd.optimization.solvers.hip_lp import linear_program_batch
+    rng = np.random.RandomState(11)
+    m, n = 40, 4
+    A = rng.randn(m, n); A /= np.linalg.norm(A, axis=1)[:, None]
+    b = 1. + rng.rand(m)
+    res = linear_program_batch(-A, A, b, relax_idx=np.arange(m, dtype=np.int32), relax_val=1., want_iters=True)
+    assert res.feasible.all()
+    for i in range(m):
+        rel = b.copy(); rel[i] += 1.
+        ref = oracle.linear_program(-A[i], A, rel)
+        assert abs(res.numpy('min')[i] - ref['min']) < 1e-6
+        x = res.numpy('argmin')[i]
+        assert (A.dot(x) - rel).max() < 1e-9
+        if abs(ref['min'] + rel[i]) > 1e-6:
+            # the optimum stops before the relaxed facet: unique vertex.  (Otherwise every point of the face
+            # {a_i x = b_i + 1} is optimal and only the value is comparable.)
+            assert np.allclose(x, ref['argmin'], rtol=1e-6, atol=1e-6)
+    # same LPs with per-problem matrices and right-hand sides (a_stride / b_stride != 0)
+    bb = np.tile(b, (m, 1)); bb[np.arange(m), np.arange(m)] += 1.
+    res2 = linear_program_batch(-A, np.tile(A, (m, 1, 1)), bb)
+    assert np.array_equal(res2.numpy('min'), res.numpy('min'))
+    assert np.array_equal(res2.numpy('argmin'), res.numpy('argmin'))

@@ -93,6 +93,47 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
                          double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream);
 
 /* -------------------------------------------------------------------------------------------------
+ * B different mpQPs of equal shape (n, m, p), each solved at its own parameter (x_stride = p) or all at one
+ * shared parameter (x_stride = 0): HybridModelPredictiveController.get_mpqp(mode_sequence).solve(x0) over a batch
+ * of mode sequences.
+ * Reference: pympc/control/controllers.py:668-680 (get_mpqp) -> pympc/optimization/parametric_programs.py:155-179
+ * (solve) -> pympc/optimization/solvers/pnnls.py:149-241, once per mode sequence.
+ * Huu [B x n x n], Hux [B x n x p], Hxx [B x p x p], fu [B x n], fx [B x p], g [B], Au [B x m x n], Ax [B x m x p],
+ * b [B x m] (the arrays pympc_condense_batch writes); X [B x p] or [p].  ws: pympc_mpqp_multi_workspace_doubles(...)
+ * doubles of device scratch.  Outputs as pympc_mpqp_solve_batch with n_out = n.
+ * ------------------------------------------------------------------------------------------------- */
+size_t pympc_mpqp_multi_workspace_doubles(int n, int m, int p, int64_t B);
+
+int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, const double *Hux, const double *Hxx,
+                           const double *fu, const double *fx, const double *g, const double *Au, const double *Ax,
+                           const double *b, const double *X, int64_t x_stride, double tol, double *ws, double *argmin,
+                           double *vmin, double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * Batched condensing of the optimal control problem of a PWA system: one mpQP per mode sequence (fp64 MFMA).
+ * Reference: pympc/control/controllers.py:682-749 (condense_optimal_control_problem) and
+ * pympc/dynamics/discrete_time_systems.py:676-751 (condense_pwa_system, productory), called by
+ * controllers.py:58-74 (ModelPredictiveController._condense_program) and :668-680 (get_mpqp).
+ * modes [B x N] int32 in [0, nm); As [nm x nx x nx], Bs [nm x nx x nu], cs [nm x nx] (c = 0 for a linear system);
+ * Q [nx x nx], R [nu x nu], P [nx x nx]; stage domains F x + G u <= h of every mode padded by the caller to rmax
+ * rows with F = 0, G = 0, h = 1: Fd [nm x rmax x nx], Gd [nm x rmax x nu], hd [nm x rmax]; terminal set
+ * FN [rN x nx], hN [rN].  With n = N nu, p = nx, m = N rmax + rN the outputs are Huu [B x n x n], Hux [B x n x p],
+ * Hxx [B x p x p], fu [B x n], fx [B x p], g [B], Au [B x m x n], Ax [B x m x p], b [B x m], optionally
+ * Sbar [B x (N+1) nx x (nx + n + 1)] = [A_bar | B_bar | c_bar] (discrete_time_systems.py:729; may be NULL) and
+ * status [B] (0, or PYMPC_BAD_MODE when a mode index is out of range: nothing else is written for that problem).
+ * ------------------------------------------------------------------------------------------------- */
+#define PYMPC_BAD_MODE 5
+
+/* Largest system the condensing kernel accepts: nx <= *nx_max, nx + N nu + 1 <= *w_max. */
+void pympc_condense_limits(int *nx_max, int *w_max);
+
+int pympc_condense_batch(int nx, int nu, int N, int nm, int rmax, int rN, const int32_t *modes, int64_t B,
+                         const double *As, const double *Bs, const double *cs, const double *Q, const double *R,
+                         const double *P, const double *Fd, const double *Gd, const double *hd, const double *FN,
+                         const double *hN, double *Huu, double *Hux, double *Hxx, double *fu, double *fx, double *g,
+                         double *Au, double *Ax, double *b, double *Sbar, int32_t *status, void *stream);
+
+/* -------------------------------------------------------------------------------------------------
  * Batched LP: B problems  min f_k'x  s.t.  A_k x <= b_k  of equal shape (n, m); equalities are folded by the
  * caller as rows (C, -C) exactly as pnnls.py:101-106 does.
  * Reference: pympc/optimization/solvers/pnnls.py:41-147 (linear_program) + :5-39 (pnnls) once per problem

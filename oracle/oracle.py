@@ -163,3 +163,34 @@ def point_location(table, X, tol=1.e-7):
     lib().oracle_point_location(_p(A), _p(b), _pi(rp), nreg, p, nu, _p(ux), _p(u0), _p(Vxx), _p(Vx), _p(V0), _p(X), B, tol,
                                 _pi(idx), _p(u), _p(V))
     return idx, u, V
+
+
+def condense(systems, domains, Q, R, P, XN_A, XN_b, mode_sequence):
+    """condense_optimal_control_problem for one mode sequence (controllers.py:682-749).
+
+    systems: list of (A, B, c); domains: list of (D_A [r x (nx+nu)], D_b [r]).  Returns a dict with Abar, Bbar, cbar,
+    Huu, Hux, Hxx, fu, fx, g, Au, Ax, b (compact rows, exactly the reference's ordering).
+    """
+    As = _d(np.array([s[0] for s in systems])); Bs = _d(np.array([s[1] for s in systems]))
+    cs = _d(np.array([s[2] for s in systems]))
+    nm, nx, nu = Bs.shape
+    z = np.ascontiguousarray(mode_sequence, np.int32)
+    N = z.size
+    dptr = np.zeros(nm + 1, np.int32)
+    dptr[1:] = np.cumsum([d[0].shape[0] for d in domains])
+    DA = _d(np.vstack([d[0] for d in domains])); Db = _d(np.concatenate([d[1] for d in domains]))
+    XA = _d(XN_A); Xb = _d(XN_b)
+    rN = XA.shape[0]
+    n = N * nu; nr = (N + 1) * nx
+    m = rN + int(sum(dptr[k + 1] - dptr[k] for k in z))
+    o = dict(Abar=np.zeros((nr, nx)), Bbar=np.zeros((nr, n)), cbar=np.zeros(nr), Huu=np.zeros((n, n)),
+             Hux=np.zeros((n, nx)), Hxx=np.zeros((nx, nx)), fu=np.zeros(n), fx=np.zeros(nx), g=np.zeros(1),
+             Au=np.zeros((m, n)), Ax=np.zeros((m, nx)), b=np.zeros(m))
+    f = lib().oracle_condense
+    f.argtypes = [ctypes.c_int] * 4 + [_ip] + [_dp] * 6 + [_ip, _dp, _dp, ctypes.c_int] + [_dp] * 14
+    rc = f(nx, nu, N, nm, _pi(z), _p(As), _p(Bs), _p(cs), _p(_d(Q)), _p(_d(R)), _p(_d(P)), _pi(dptr), _p(DA), _p(Db), rN,
+           _p(XA), _p(Xb), *[_p(o[k]) for k in ('Abar', 'Bbar', 'cbar', 'Huu', 'Hux', 'Hxx', 'fu', 'fx', 'g', 'Au', 'Ax', 'b')])
+    if rc != m:
+        raise ValueError('bad mode sequence')
+    o['g'] = float(o['g'][0])
+    return o

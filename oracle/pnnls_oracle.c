@@ -15,6 +15,8 @@
  *   oracle_point_location
  *                    pympc/optimization/parametric_programs.py:442-532, 349-400 and
  *                    pympc/geometry/polyhedron.py:578-604 (contains)
+ *   oracle_condense  pympc/dynamics/discrete_time_systems.py:676-751 (condense_pwa_system) and
+ *                    pympc/control/controllers.py:682-749 (condense_optimal_control_problem)
  *   oracle_nnls      scipy.optimize.nnls -- THIRD-PARTY, absent from /root/reference.
  *                    The reference pins scipy<=1.11.4 (setup.py:18, requirements.txt:1), i.e. the
  *                    f2py-wrapped Fortran NNLS of Lawson & Hanson, "Solving Least Squares Problems"
@@ -633,4 +635,157 @@ int oracle_point_location(const double *A, const double *b, const int *row_ptr, 
         }
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Condensing of the optimal control problem for one mode sequence                              */
+/* pympc/dynamics/discrete_time_systems.py:676-751 (condense_pwa_system, productory) and        */
+/* pympc/control/controllers.py:682-749 (condense_optimal_control_problem), restated with the   */
+/* same dense stacked matrices (Q_bar, R_bar, F_bar, G_bar) the reference forms.                */
+/* ------------------------------------------------------------------------------------------- */
+
+/* C[r x c] = A[r x k] B[k x c] */
+static void mat_mul(const double *A, const double *B, int r, int k, int c, double *C)
+{
+    for (int i = 0; i < r; ++i)
+        for (int j = 0; j < c; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < k; ++q) s += A[i * k + q] * B[q * c + j];
+            C[i * c + j] = s;
+        }
+}
+
+/* productory(A_sequence[i:j:-1]) = A_{z(i)} A_{z(i-1)} ... A_{z(j+1)}  (j = -1: down to index 0); identity if empty */
+static void productory_desc(const double *As, const int *z, int nx, int i, int j, double *M, double *tmp)
+{
+    for (int a = 0; a < nx * nx; ++a) M[a] = (a / nx == a % nx) ? 1.0 : 0.0;
+    for (int t = i; t > j; --t) { /* left to right: M = M * A_{z(t)} */
+        mat_mul(M, As + (size_t)z[t] * nx * nx, nx, nx, nx, tmp);
+        memcpy(M, tmp, sizeof(double) * nx * nx);
+    }
+}
+
+/*
+ * modes z[N]; systems As [nm x nx x nx], Bs [nm x nx x nu], cs [nm x nx]; Q, R, P; stage domains of mode i are rows
+ * dptr[i] .. dptr[i+1]-1 of DA [. x (nx+nu)], Db [.]; terminal set XA [rN x nx], Xb [rN].
+ * Outputs: Abar [(N+1)nx x nx], Bbar [(N+1)nx x N nu], cbar [(N+1)nx], Huu [n x n], Hux [n x nx], Hxx [nx x nx],
+ * fu [n], fx [nx], g [1], Au [m x n], Ax [m x nx], b [m],  m = sum_t rows(z[t]) + rN (the caller sizes them).
+ */
+int oracle_condense(int nx, int nu, int N, int nm, const int *z, const double *As, const double *Bs, const double *cs,
+                    const double *Q, const double *R, const double *P, const int *dptr, const double *DA,
+                    const double *Db, int rN, const double *XA, const double *Xb, double *Abar, double *Bbar,
+                    double *cbar, double *Huu, double *Hux, double *Hxx, double *fu, double *fx, double *g, double *Au,
+                    double *Ax, double *b)
+{
+    const int n = N * nu, nr = (N + 1) * nx;
+    for (int t = 0; t < N; ++t)
+        if (z[t] < 0 || z[t] >= nm) return -1;
+    double *M = (double *)malloc(sizeof(double) * nx * nx), *tmp = (double *)malloc(sizeof(double) * nx * nx);
+    double *v = (double *)malloc(sizeof(double) * nx * (nu > 1 ? nu : 1));
+    /* free evolution (discrete_time_systems.py:712-713) */
+    memset(Abar, 0, sizeof(double) * nr * nx);
+    for (int i = 0; i < nx; ++i) Abar[i * nx + i] = 1.0;
+    for (int i = 0; i < N; ++i) {
+        productory_desc(As, z, nx, i, -1, M, tmp);
+        memcpy(Abar + (size_t)(i + 1) * nx * nx, M, sizeof(double) * nx * nx);
+    }
+    /* forced evolution (:716-721) */
+    memset(Bbar, 0, sizeof(double) * nr * n);
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            if (j < i) {
+                productory_desc(As, z, nx, i, j, M, tmp);
+                mat_mul(M, Bs + (size_t)z[j] * nx * nu, nx, nx, nu, v);
+            } else {
+                memcpy(v, Bs + (size_t)z[i] * nx * nu, sizeof(double) * nx * nu);
+            }
+            for (int r = 0; r < nx; ++r)
+                for (int c = 0; c < nu; ++c) Bbar[(size_t)((i + 1) * nx + r) * n + j * nu + c] = v[r * nu + c];
+        }
+    }
+    /* offset term (:724-727) */
+    memset(cbar, 0, sizeof(double) * nr);
+    for (int i = 0; i < N; ++i) {
+        double *ci = cbar + (size_t)(i + 1) * nx;
+        for (int j = 0; j < i; ++j) {
+            productory_desc(As, z, nx, i, j, M, tmp);
+            mat_mul(M, cs + (size_t)z[j] * nx, nx, nx, 1, v);
+            for (int r = 0; r < nx; ++r) ci[r] += v[r];
+        }
+        for (int r = 0; r < nx; ++r) ci[r] += cs[(size_t)z[i] * nx + r];
+    }
+    free(M); free(tmp); free(v);
+
+    /* stacked cost matrices (controllers.py:716-719) and the blocks of the objective (:722-731) */
+    double *Qbar = (double *)calloc((size_t)nr * nr, sizeof(double));
+    for (int t = 0; t <= N; ++t) {
+        const double *Qt = (t == N) ? P : Q;
+        for (int r = 0; r < nx; ++r)
+            for (int c = 0; c < nx; ++c) Qbar[(size_t)(t * nx + r) * nr + t * nx + c] = Qt[r * nx + c];
+    }
+    double *QB = (double *)malloc(sizeof(double) * nr * n), *QA = (double *)malloc(sizeof(double) * nr * nx);
+    double *Qc = (double *)malloc(sizeof(double) * nr);
+    mat_mul(Qbar, Bbar, nr, nr, n, QB);
+    mat_mul(Qbar, Abar, nr, nr, nx, QA);
+    mat_mul(Qbar, cbar, nr, nr, 1, Qc);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < nr; ++q) s += Bbar[(size_t)q * n + i] * QB[(size_t)q * n + j];
+            Huu[i * n + j] = s + ((i / nu == j / nu) ? R[(i % nu) * nu + (j % nu)] : 0.0);
+        }
+        for (int j = 0; j < nx; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < nr; ++q) s += Bbar[(size_t)q * n + i] * QA[(size_t)q * nx + j];
+            Hux[i * nx + j] = s;
+        }
+        double s = 0.0;
+        for (int q = 0; q < nr; ++q) s += Bbar[(size_t)q * n + i] * Qc[q];
+        fu[i] = s;
+    }
+    for (int i = 0; i < nx; ++i) {
+        for (int j = 0; j < nx; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < nr; ++q) s += Abar[(size_t)q * nx + i] * QA[(size_t)q * nx + j];
+            Hxx[i * nx + j] = s;
+        }
+        double s = 0.0;
+        for (int q = 0; q < nr; ++q) s += Abar[(size_t)q * nx + i] * Qc[q];
+        fx[i] = s;
+    }
+    {
+        double s = 0.0;
+        for (int q = 0; q < nr; ++q) s += cbar[q] * Qc[q];
+        *g = 0.5 * s;
+    }
+    free(Qbar); free(QB); free(QA); free(Qc);
+
+    /* stacked constraints (controllers.py:733-747) */
+    int m = rN;
+    for (int t = 0; t < N; ++t) m += dptr[z[t] + 1] - dptr[z[t]];
+    double *Fbar = (double *)calloc((size_t)m * nr, sizeof(double));
+    double *Gbar = (double *)calloc((size_t)m * (n > 0 ? n : 1), sizeof(double));
+    double *hbar = (double *)malloc(sizeof(double) * (m > 0 ? m : 1));
+    int row = 0;
+    for (int t = 0; t <= N; ++t) {
+        if (t < N) {
+            for (int r = dptr[z[t]]; r < dptr[z[t] + 1]; ++r, ++row) {
+                for (int c = 0; c < nx; ++c) Fbar[(size_t)row * nr + t * nx + c] = DA[(size_t)r * (nx + nu) + c];
+                for (int c = 0; c < nu; ++c) Gbar[(size_t)row * n + t * nu + c] = DA[(size_t)r * (nx + nu) + nx + c];
+                hbar[row] = Db[r];
+            }
+        } else {
+            for (int r = 0; r < rN; ++r, ++row) {
+                for (int c = 0; c < nx; ++c) Fbar[(size_t)row * nr + N * nx + c] = XA[(size_t)r * nx + c];
+                hbar[row] = Xb[r];
+            }
+        }
+    }
+    mat_mul(Fbar, Bbar, m, nr, n, Au);
+    for (size_t e = 0; e < (size_t)m * n; ++e) Au[e] += Gbar[e];
+    mat_mul(Fbar, Abar, m, nr, nx, Ax);
+    mat_mul(Fbar, cbar, m, nr, 1, b);
+    for (int r = 0; r < m; ++r) b[r] = hbar[r] - b[r];
+    free(Fbar); free(Gbar); free(hbar);
+    return m;
 }

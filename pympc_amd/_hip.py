@@ -11,7 +11,7 @@ import torch
 
 from .build import LIB_PATH
 
-OPTIMAL, INFEASIBLE, MAXITER, NOT_PD = 0, 1, 3, 4
+OPTIMAL, INFEASIBLE, MAXITER, NOT_PD, BAD_MODE = 0, 1, 3, 4, 5
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -29,6 +29,10 @@ SIGNATURES = {
     "pympc_qp_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i64]),
     "pympc_qp_solve_batch": (_i, [_i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp]),
+    "pympc_mpqp_multi_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i, _i64]),
+    "pympc_mpqp_multi_solve": (_i, [_i, _i, _i, _i64] + [_vp] * 10 + [_i64, _d] + [_vp] * 8),
+    "pympc_condense_limits": (None, [ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "pympc_condense_batch": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i64] + [_vp] * 23),
     "pympc_lp_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i64, _i]),
     "pympc_lp_limits": (None, [ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "pympc_lp_solve_batch": (_i, [_i, _i, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -1,0 +1,183 @@
+"""MPC controllers on the batched HIP path, mirroring /root/reference/pympc/control/controllers.py.
+
+    ModelPredictiveController(S, N, Q, R, P, D, X_N)            :11-250
+        feedforward(x) / feedback(x)                            :76-124    x 1-D: reference semantics (None when
+                                                                           infeasible); x [B x nx]: one launch, arrays
+        store_explicit_solution / feedforward_explicit / feedback_explicit   :126-186
+    HybridModelPredictiveController(S, N, Q, R, P, X_N)         :252-680   fixed-mode-sequence side only:
+        get_mpqp(mode_sequence)                                 :668-680
+        get_mpqp_batch(mode_sequences) / solve_mode_sequences(x, mode_sequences)      (batched, new)
+    condense_optimal_control_problem(S, Q, R, P, X_N, mode_sequence)                :682-749
+
+The mixed-integer feedback of the hybrid controller (big-M MIQP through Gurobi, :289-666) is outside the pnnls path.
+"""
+import numpy as np
+import torch
+
+from ..dynamics.discrete_time_systems import AffineSystem, PieceWiseAffineSystem
+from .condense import PwaTables, condense_batch
+
+
+def _is_batch(x):
+    return (isinstance(x, torch.Tensor) and x.dim() == 2) or (not isinstance(x, torch.Tensor) and np.ndim(x) == 2)
+
+
+class ModelPredictiveController(object):
+    """
+    Linear MPC: V*(x0) = min 1/2 sum_{t<N} (x'Qx + u'Ru) + 1/2 x_N'P x_N  s.t. x+ = A x + B u, (x, u) in D, x_N in X_N.
+    """
+
+    def __init__(self, S, N, Q, R, P, D, X_N):
+        self.S = S
+        self.N = N
+        self.Q = Q
+        self.R = R
+        self.P = P
+        self.D = D
+        self.X_N = X_N
+        self.explicit_solution = None
+        self.mpqp = self._condense_program()
+
+    def _condense_program(self):
+        """Condensed mpQP of the optimal control problem: the PWA condenser with a single mode (:58-74)."""
+        S = PieceWiseAffineSystem([AffineSystem(self.S.A, self.S.B, np.zeros(self.S.nx))], [self.D])
+        return condense_optimal_control_problem(S, self.Q, self.R, self.P, self.X_N, [0] * self.N)
+
+    # ------------------------------------------------------------------ implicit (online QP)
+    def feedforward(self, x):
+        """
+        x 1-D: (list of the N optimal inputs, V) or (None, None) when infeasible (:76-102).
+        x [B x nx]: (U [B x N x nu], V [B], feasible [B] bool) as host arrays; infeasible rows hold NaN.
+        """
+        if _is_batch(x):
+            res = self.mpqp.solve(x, want_mult=False, want_active=False)
+            U = res.numpy('argmin').reshape(len(res), self.N, self.S.nu)
+            return U, res.numpy('min'), res.feasible
+        sol = self.mpqp.solve(x)
+        if sol['min'] is None:
+            return None, None
+        nu = self.S.nu
+        return [sol['argmin'][nu * t:nu * (t + 1)] for t in range(self.N)], sol['min']
+
+    def feedback(self, x):
+        """
+        x 1-D: first optimal input or None (:104-124).  x [B x nx]: [B x nu] array with NaN rows where infeasible
+        (only u(0) leaves the device).
+        """
+        if _is_batch(x):
+            return self.feedback_batch(x).numpy('argmin')
+        u = self.feedforward(x)[0]
+        return None if u is None else u[0]
+
+    def feedback_batch(self, X, **kwargs):
+        """Device-resident batched feedback: BatchResult with argmin = u(0) [B x nu], min = V, status; nothing is
+        synchronised or copied.  This is the call the headline benchmark times."""
+        kwargs.setdefault('want_mult', False)
+        kwargs.setdefault('want_active', False)
+        return self.mpqp.solve(X, n_out=self.S.nu, **kwargs)
+
+    # ------------------------------------------------------------------ explicit (table look-up)
+    def store_explicit_solution(self, samples=None, **kwargs):
+        """
+        Stores the explicit solution of the condensed mpQP (:126-136).  The table is built from the active sets the
+        batched QP path finds at `samples` [B x nx] (default: a grid over the bounding box of the state constraints).
+        """
+        if samples is None:
+            samples = self._default_samples()
+        self.explicit_solution = self.mpqp.explicit_solve_from_samples(samples, **kwargs)
+
+    def _default_samples(self, per_axis=None):
+        nx = self.S.nx
+        box = self.D.A[:, nx:] == 0.
+        lo = np.full(nx, -1.); hi = np.full(nx, 1.)
+        for row, keep in zip(range(self.D.A.shape[0]), box.all(axis=1)):
+            a = self.D.A[row, :nx]
+            nz = np.flatnonzero(a)
+            if keep and nz.size == 1:
+                i = nz[0]
+                bound = self.D.b[row] / a[i]
+                if a[i] > 0:
+                    hi[i] = bound
+                else:
+                    lo[i] = bound
+        per_axis = per_axis or max(5, int(round(40000 ** (1. / nx))))
+        axes = [np.linspace(lo[i], hi[i], per_axis) for i in range(nx)]
+        return np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, nx)
+
+    def feedforward_explicit(self, x):
+        """(u, V) from the stored table (:138-164); batch: (U [B x N x nu], V [B], region index [B])."""
+        if self.explicit_solution is None:
+            raise ValueError('explicit solution not stored.')
+        nu = self.S.nu
+        if _is_batch(x):
+            idx, U, V = self.explicit_solution.locate(x)
+            return U.cpu().numpy().reshape(-1, self.N, nu), V.cpu().numpy(), idx.cpu().numpy()
+        u = self.explicit_solution.u(x)
+        if u is not None:
+            u = [u[t * nu:(t + 1) * nu] for t in range(self.N)]
+        return u, self.explicit_solution.V(x)
+
+    def feedback_explicit(self, x):
+        """First input from the stored table (:166-186); batch: [B x nu] with NaN rows where uncovered."""
+        if self.explicit_solution is None:
+            raise ValueError('explicit solution not stored.')
+        if _is_batch(x):
+            return self.explicit_solution.locate(x, nu=self.S.nu)[1].cpu().numpy()
+        u = self.feedforward_explicit(x)[0]
+        return None if u is None else u[0]
+
+
+class HybridModelPredictiveController(object):
+    """
+    Hybrid MPC for PWA systems, restricted to what runs through the pnnls path in the reference: the convex QP of a
+    FIXED mode sequence (get_mpqp, :668-680).  The batched forms condense and solve many mode sequences at once.
+    """
+
+    def __init__(self, S, N, Q, R, P, X_N):
+        self.S = S
+        self.N = N
+        self.Q = Q
+        self.R = R
+        self.P = P
+        self.X_N = X_N
+        self._tables = None
+
+    def tables(self):
+        if self._tables is None:
+            self._tables = PwaTables(self.S.affine_systems, self.S.domains, self.Q, self.R, self.P, self.X_N)
+        return self._tables
+
+    def get_mpqp(self, mode_sequence):
+        return condense_optimal_control_problem(self.S, self.Q, self.R, self.P, self.X_N, mode_sequence, self.tables())
+
+    def get_mpqp_batch(self, mode_sequences):
+        """Condenses every row of mode_sequences [B x N] in one launch -> MpqpBatch (device)."""
+        return condense_batch(self.tables(), mode_sequences)
+
+    def solve_mode_sequences(self, x, mode_sequences, **kwargs):
+        """get_mpqp(ms).solve(x) for every row ms of mode_sequences; returns (BatchResult, MpqpBatch)."""
+        batch = self.get_mpqp_batch(mode_sequences)
+        return batch.solve(x, **kwargs), batch
+
+    def feedforward_over(self, x, mode_sequences):
+        """
+        Best fixed-mode-sequence solution among the given candidates: (u list, V, mode_sequence) of the feasible
+        sequence with the lowest cost, or (None, None, None).  (The reference obtains the same optimum from its MIQP,
+        test_controllers.py:270-289.)
+        """
+        res, batch = self.solve_mode_sequences(x, mode_sequences, want_mult=False, want_active=False)
+        V = torch.where(res.t['status'] == 0, res.t['min'], torch.full_like(res.t['min'], float('inf')))
+        k = int(torch.argmin(V).item())
+        if not np.isfinite(float(V[k].item())):
+            return None, None, None
+        u = res.t['argmin'][k].cpu().numpy()
+        nu = self.S.nu
+        return [u[t * nu:(t + 1) * nu] for t in range(self.N)], float(V[k].item()), [int(z) for z in batch.modes[k].cpu().numpy()]
+
+
+def condense_optimal_control_problem(S, Q, R, P, X_N, mode_sequence, tables=None):
+    """Condensed mpQP of the PWA optimal control problem for one mode sequence (:682-749), by the MFMA kernel."""
+    if tables is None:
+        tables = PwaTables(S.affine_systems, S.domains, Q, R, P, X_N)
+    batch = condense_batch(tables, np.asarray(mode_sequence, dtype=np.int32).reshape(1, -1))
+    return batch.get(0)

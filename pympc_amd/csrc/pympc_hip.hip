@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../include/pympc_hip.h"
+#include "condense.hpp"
 #include "lp_block.hpp"
 #include "point_location.hpp"
 #include "qp_prepare.hpp"
@@ -123,7 +124,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
 
 extern "C" {
 
-int pympc_hip_abi_version(void) { return 1; }
+int pympc_hip_abi_version(void) { return 2; }
 
 const char *pympc_hip_last_error(void) { return g_err; }
 
@@ -169,7 +170,7 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
     SolveParams P;
     memset(&P, 0, sizeof(P));
     P.ws = ws; P.ws_stride = 0; P.ws_status = nullptr;
-    P.X = X; P.B = B; P.tol = tol; P.n_out = n_out;
+    P.X = X; P.x_stride = p; P.B = B; P.tol = tol; P.n_out = n_out;
     P.argmin = n_out > 0 ? argmin : nullptr;
     P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
     return solve_common(true, n, m, p, P, (hipStream_t)stream);
@@ -211,6 +212,98 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
     P.X = nullptr; P.B = B; P.tol = tol; P.n_out = n;
     P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
     return solve_common(false, n, m, 0, P, (hipStream_t)stream);
+}
+
+size_t pympc_mpqp_multi_workspace_doubles(int n, int m, int p, int64_t B)
+{
+    if (n < 1 || m < 1 || p < 0 || n > kNMax || m > kMMax || B < 0) return 0;
+    return ws_layout(n, m, p).total * (size_t)B + ((size_t)B + 1) / 2 + 32;
+}
+
+int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, const double *Hux, const double *Hxx,
+                           const double *fu, const double *fx, const double *g, const double *Au, const double *Ax,
+                           const double *b, const double *X, int64_t x_stride, double tol, double *ws, double *argmin,
+                           double *vmin, double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream)
+{
+    if (int rc = check_shape(n, m, p)) return rc;
+    if (B < 0 || !Huu || !fu || !Au || !b || !g || !ws || !status || (p > 0 && (!Hux || !Hxx || !fx || !Ax || !X)))
+        return fail(PYMPC_ERR_ARG, "pympc_mpqp_multi_solve: null pointer");
+    if (x_stride != 0 && x_stride < p) return fail(PYMPC_ERR_ARG, "x_stride %lld < p", (long long)x_stride);
+    if (B == 0) return 0;
+    if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    const WsLayout L = ws_layout(n, m, p);
+    int32_t *ws_status = reinterpret_cast<int32_t *>(ws + L.total * (size_t)B);
+    PrepParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.n = n; Q.m = m; Q.p = p; Q.L = L;
+    Q.H = Huu; Q.h_stride = (long long)n * n;
+    Q.Hux = Hux; Q.hux_stride = (long long)n * p;
+    Q.Hxx = Hxx; Q.hxx_stride = (long long)p * p;
+    Q.fu = fu; Q.fu_stride = n;
+    Q.fx = fx; Q.fx_stride = p;
+    Q.gs = g; Q.g_stride = 1;
+    Q.A = Au; Q.a_stride = (long long)m * n;
+    Q.Ax = Ax; Q.ax_stride = (long long)m * p;
+    Q.b = b; Q.b_stride = m;
+    Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
+    const size_t lds = (size_t)3 * n * (n + 1) * 8;
+    if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(n * n >= 1024 ? 256 : 64), lds, (hipStream_t)stream, Q);
+    if (int rc = check_launch("qp_prepare_kernel")) return rc;
+    SolveParams P;
+    memset(&P, 0, sizeof(P));
+    P.ws = ws; P.ws_stride = (long long)L.total; P.ws_status = ws_status;
+    P.X = p > 0 ? X : nullptr; P.x_stride = x_stride; P.B = B; P.tol = tol; P.n_out = n;
+    P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
+    return solve_common(false, n, m, p, P, (hipStream_t)stream);
+}
+
+void pympc_condense_limits(int *nx_max, int *w_max)
+{
+    if (nx_max) *nx_max = kCondNxMax;
+    if (w_max) *w_max = 16 * kCondCtMax;
+}
+
+int pympc_condense_batch(int nx, int nu, int N, int nm, int rmax, int rN, const int32_t *modes, int64_t B,
+                         const double *As, const double *Bs, const double *cs, const double *Q, const double *R,
+                         const double *P, const double *Fd, const double *Gd, const double *hd, const double *FN,
+                         const double *hN, double *Huu, double *Hux, double *Hxx, double *fu, double *fx, double *g,
+                         double *Au, double *Ax, double *b, double *Sbar, int32_t *status, void *stream)
+{
+    if (nx < 1 || nu < 1 || N < 1 || nm < 1 || rmax < 0 || rN < 0 || B < 0)
+        return fail(PYMPC_ERR_ARG, "pympc_condense_batch: bad shape");
+    const int W = nx + N * nu + 1;
+    if (nx > kCondNxMax) return fail(PYMPC_ERR_UNSUPPORTED, "nx=%d exceeds the condensing kernel's limit of %d states", nx, kCondNxMax);
+    if (W > 16 * kCondCtMax)
+        return fail(PYMPC_ERR_UNSUPPORTED, "nx + N nu + 1 = %d exceeds the condensing kernel's limit of %d columns", W, 16 * kCondCtMax);
+    if (!modes || !As || !Bs || !cs || !Q || !R || !P || (rmax > 0 && (!Fd || !Gd || !hd)) || (rN > 0 && (!FN || !hN)) ||
+        !Huu || !Hux || !Hxx || !fu || !fx || !g || !status || (N * rmax + rN > 0 && (!Au || !Ax || !b)))
+        return fail(PYMPC_ERR_ARG, "pympc_condense_batch: null pointer");
+    if (B == 0) return 0;
+    if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    CondParams C;
+    memset(&C, 0, sizeof(C));
+    C.nx = nx; C.nu = nu; C.N = N; C.nm = nm; C.rmax = rmax; C.rN = rN;
+    C.n = N * nu; C.m = N * rmax + rN; C.W = W; C.CT = (W + 15) / 16;
+    C.pitch = (16 * C.CT) | 16;   // odd multiple of 16 doubles: consecutive rows start 32 banks apart
+    C.modes = modes; C.As = As; C.Bs = Bs; C.cs = cs; C.Q = Q; C.R = R; C.P = P;
+    C.Fd = Fd; C.Gd = Gd; C.hd = hd; C.FN = FN; C.hN = hN; C.B = B;
+    C.Huu = Huu; C.Hux = Hux; C.Hxx = Hxx; C.fu = fu; C.fx = fx; C.g = g; C.Au = Au; C.Ax = Ax; C.b = b;
+    C.Sbar = Sbar; C.status = status;
+    const size_t lds = (size_t)(N + 1) * nx * C.pitch * 8;
+    if (lds > kLdsBytes) return fail(PYMPC_ERR_UNSUPPORTED, "prediction matrices (%zu B) do not fit the 160 KiB LDS", lds);
+    hipStream_t st = (hipStream_t)stream;
+#define PYMPC_COND_CASE(KS)                                                                  \
+    case KS: {                                                                               \
+        if (int rc = allow_lds(condense_kernel<KS>, lds)) return rc;                         \
+        hipLaunchKernelGGL(condense_kernel<KS>, dim3((unsigned)B), dim3(64), lds, st, C);    \
+        break;                                                                               \
+    }
+    switch ((nx + 3) / 4) {
+        PYMPC_COND_CASE(1) PYMPC_COND_CASE(2) PYMPC_COND_CASE(3) PYMPC_COND_CASE(4)
+    }
+#undef PYMPC_COND_CASE
+    return check_launch("condense_kernel");
 }
 
 size_t pympc_lp_workspace_doubles(int n, int m, int64_t B, int a_shared)

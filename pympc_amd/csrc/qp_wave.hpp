@@ -35,6 +35,7 @@ struct SolveParams {
     long long ws_stride;        // doubles between problems' workspaces (0: one shared workspace)
     const int32_t *ws_status;   // per-workspace prepare status (may be null); stride 1 if ws_stride != 0
     const double *X;            // [B x p] or null when p == 0
+    long long x_stride;         // doubles between problems' parameter vectors (0: one shared x)
     long long B;
     double tol;
     int n_out;
@@ -105,7 +106,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     double *rb = ab + R;
     double *ub = rb + R;
     uint32_t *bits = reinterpret_cast<uint32_t *>(ub + n);
-    const double *x0 = P.X ? P.X + prob * p : nullptr;
+    const double *x0 = P.X ? P.X + prob * P.x_stride : nullptr;
 
     // ---- m(x) = m0 + Gm' x : the per-problem row of the NNLS matrix (pnnls.py:214)
     double mv[MT], w[MT];

@@ -79,30 +79,14 @@ class ModelPredictiveController(object):
     # ------------------------------------------------------------------ explicit (table look-up)
     def store_explicit_solution(self, samples=None, **kwargs):
         """
-        Stores the explicit solution of the condensed mpQP (:126-136).  The table is built from the active sets the
-        batched QP path finds at `samples` [B x nx] (default: a grid over the bounding box of the state constraints).
+        Stores the explicit solution of the condensed mpQP (:126-136): facet-flipping exploration as in the reference
+        (kwargs: step_size, verbose), or, with samples [B x nx], the table of the active sets the batched QP path finds
+        at those points (one launch; regions in order of first appearance).
         """
         if samples is None:
-            samples = self._default_samples()
-        self.explicit_solution = self.mpqp.explicit_solve_from_samples(samples, **kwargs)
-
-    def _default_samples(self, per_axis=None):
-        nx = self.S.nx
-        box = self.D.A[:, nx:] == 0.
-        lo = np.full(nx, -1.); hi = np.full(nx, 1.)
-        for row, keep in zip(range(self.D.A.shape[0]), box.all(axis=1)):
-            a = self.D.A[row, :nx]
-            nz = np.flatnonzero(a)
-            if keep and nz.size == 1:
-                i = nz[0]
-                bound = self.D.b[row] / a[i]
-                if a[i] > 0:
-                    hi[i] = bound
-                else:
-                    lo[i] = bound
-        per_axis = per_axis or max(5, int(round(40000 ** (1. / nx))))
-        axes = [np.linspace(lo[i], hi[i], per_axis) for i in range(nx)]
-        return np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, nx)
+            self.explicit_solution = self.mpqp.explicit_solve(**kwargs)
+        else:
+            self.explicit_solution = self.mpqp.explicit_solve_from_samples(samples, **kwargs)
 
     def feedforward_explicit(self, x):
         """(u, V) from the stored table (:138-164); batch: (U [B x N x nu], V [B], region index [B])."""

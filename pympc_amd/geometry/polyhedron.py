@@ -260,6 +260,16 @@ class Polyhedron(object):
         elif n <= n_max and m_qp <= m_max:
             sol = quadratic_program(np.eye(n), np.zeros(n), self.A, self.b, self.C, self.d)
             self._empty = sol['min'] is None
+        elif self.C.shape[0] > 0 and n > min(n_max, _hip.lp_limits()[0]):
+            # more variables than a wavefront holds: same decision in the null space of the equalities
+            try:
+                E, f, _, _ = self._remove_equalities()
+            except ValueError:
+                # no null space, or dependent equalities: C x = d has at most the least-squares point
+                x = np.linalg.lstsq(self.C, self.d, rcond=None)[0]
+                self._empty = not (np.allclose(self.C.dot(x), self.d, atol=1e-9) and np.all(self.A.dot(x) <= self.b + 1e-9))
+            else:
+                self._empty = Polyhedron(E, f).empty
         else:
             # more rows than the wave-per-QP kernel holds: same decision from the feasibility LP min 0'x
             sol = linear_program(np.zeros(n), self.A, self.b, self.C, self.d)

@@ -8,6 +8,8 @@
 
 The numerical work of solve() and of the batched look-ups runs in the HIP kernels (one launch per batch).
 """
+from copy import copy
+
 import numpy as np
 import torch
 
@@ -94,6 +96,55 @@ class MultiParametricQuadraticProgram(object):
         V0 = .5 * u0.dot(Huu).dot(u0) + fu.dot(u0) + self.g
         return CriticalRegion(active_set, {'x': ux, '0': u0}, {'x': px, '0': p0}, {'xx': Vxx, 'x': Vx, '0': V0}, cr)
 
+    def explicit_solve_given_point(self, x, active_set_guess=None, verbose=False):
+        """
+        Critical region that covers x (None if x is infeasible), parametric_programs.py:118-153: try the guessed
+        active set first, otherwise solve the QP at x for the active set.
+        """
+        if active_set_guess is not None:
+            cr = self.explicit_solve_given_active_set(active_set_guess)
+            if cr is not None and cr.contains(x):
+                return cr
+            if verbose:
+                print('Wrong active-set guess:')
+        sol = self.solve(x)
+        if sol['active_set'] is None:
+            if verbose:
+                print('unfeasible sample.')
+            return None
+        if verbose:
+            print('feasible sample with active set ' + str(sol['active_set']) + '.')
+        return self.explicit_solve_given_active_set(sol['active_set'])
+
+    def explicit_solve(self, step_size=1.e-5, verbose=False):
+        """
+        Explicit solution by facet flipping (parametric_programs.py:181-241): start at the origin, and for every
+        critical region found step across each of its minimal facets (from the Chebyshev centre of the facet) with the
+        active set guessed by toggling that facet's constraint.  Regions are listed in the order of discovery, which
+        is the order the look-up scans.  Every LP / QP inside (redundancy removal, facet centres, active sets) runs
+        on the HIP solvers; the exploration itself is a sequential host loop, as in the reference.
+        """
+        x_buffer = [(np.zeros(self.f['x'].size), [])]
+        crs_found = []
+        while len(x_buffer) > 0:
+            x_buffer = [c for c in x_buffer if not any(cr.contains(c[0]) for cr in crs_found)]
+            if len(x_buffer) == 0:
+                break
+            x, guess = x_buffer.pop(0)
+            cr = self.explicit_solve_given_point(x, guess, verbose)
+            if cr is None:
+                continue
+            for i in cr.minimal_facets():
+                step = cr.facet_center(i) + step_size * cr.A[i]
+                flipped = set(cr.active_set).symmetric_difference({i})
+                x_buffer.append((step, sorted(flipped)))
+            crs_found.append(cr)
+            if verbose:
+                print('CR found, active set: ' + str(cr.active_set) + '.')
+        if verbose:
+            print('Explicit solution found, CRs are: ' + str(len(crs_found)) + '.')
+        return ExplicitSolution(crs_found)
+
     def explicit_solve_from_samples(self, X, max_regions=None):
         """
         Builds an ExplicitSolution from the active sets the batched QP path finds at the sample points X [B x p]
@@ -135,6 +186,15 @@ class CriticalRegion(object):
 
     def minimal_facets(self):
         return self.polyhedron.minimal_facets()
+
+    def facet_center(self, i):
+        """Chebyshev centre of the i-th facet: the region with row i added as an equality (parametric_programs.py:320-347)."""
+        P = self.polyhedron
+        if P.A.shape[1] == 1:
+            return P.b.flatten()[i] / P.A[i][0]
+        facet = copy(P)
+        facet.add_equality(facet.A[i:i + 1, :], facet.b[i:i + 1])
+        return facet.center
 
     def u(self, x):
         return self._u['x'].dot(x) + self._u['0']

@@ -144,3 +144,35 @@ def test_lp_batch_shared_matrix_relaxation(oracle):
     res2 = linear_program_batch(-A, np.tile(A, (m, 1, 1)), bb)
     assert np.array_equal(res2.numpy('min'), res.numpy('min'))
     assert np.array_equal(res2.numpy('argmin'), res.numpy('argmin'))
+
+
+@pytest.mark.parametrize("m", [1000, 10000])
+def test_full_size_polytope_properties(m):
+    """Config C3 at full size (SURVEY 8d recipe: A = randn(m, 6) row-normalised, b = 1 + rand(m), seed 0).  The
+    reference needs a dense (1+m+n) x 2m matrix per LP (1.6 GB at m = 10 000), so parity is checked through
+    size-independent properties and an independent computation: the non-redundant facets of a bounded full-dimensional
+    polytope are exactly the facets that carry >= n vertices, and qhull enumerates the vertices."""
+    from scipy.spatial import HalfspaceIntersection
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    from pympc_amd.optimization.solvers.hip_lp import linear_program_batch
+    rng = np.random.RandomState(0)
+    A = rng.randn(m, 6); A /= np.linalg.norm(A, axis=1)[:, None]
+    b = 1. + rng.rand(m)
+    P = Polyhedron(A.copy(), b.copy())
+    mf = P.minimal_facets()
+    r, c = P.radius, P.center
+    # Chebyshev ball: inside, touches >= n + 1 = 7 facets (generic data), multipliers certify optimality
+    slack = b - A.dot(c)
+    assert slack.min() >= r - 1e-9 and (np.abs(slack - r) < 1e-8).sum() >= 7
+    V = HalfspaceIntersection(np.hstack((A, -b[:, None])), c).intersections
+    on = np.abs(V.dot(A.T) - b) < 1e-9
+    assert mf == [int(i) for i in np.where(on.sum(axis=0) >= 6)[0]]          # bit-exact index list
+    # idempotence and in-place semantics of remove_redundant_inequalities (polyhedron.py:452-466)
+    P.remove_redundant_inequalities()
+    assert np.array_equal(P.A, A[mf]) and np.array_equal(P.b, b[mf])
+    assert Polyhedron(P.A.copy(), P.b.copy()).minimal_facets() == list(range(len(mf)))
+    # every vertex of the polytope satisfies the reduced description, every dropped facet is implied by it:
+    # max a_i x over the reduced set <= b_i
+    dropped = np.setdiff1d(np.arange(m), mf)[:512]
+    res = linear_program_batch(-A[dropped], P.A, P.b, want_argmin=False, want_mult=False, want_active=False)
+    assert res.feasible.all() and np.all(-res.numpy('min') <= b[dropped] + 1e-7)

@@ -81,8 +81,8 @@ __global__ void lp_prepare_kernel(LpPrepParams P)
 __host__ __device__ inline size_t lp_lds_doubles(int n, int m, int RP, int nwaves)
 {
     const size_t nw = (size_t)(m + 31) / 32;
-    // Qt, Wi, cv, ab, rb, xb, tb, + ctl (8) + per-wave slots (2 x 2 x nwaves) + bitmap words (2 x nw uint32) + rej
-    return (size_t)2 * n * RP + 5 * (size_t)n + 8 + 4 * (size_t)nwaves + nw + (kLpRejMax + 1) / 2 + 2;
+    // Q, Wi, cv, ab | rb, tb, yb (padded) | ctl (8) + per-wave slots (2 x 2 x nwaves) + bitmap words (2 x nw uint32) + rej
+    return (size_t)invqr_lds_doubles(n, RP) + 3 * (size_t)(n + kVecPad) + 8 + 4 * (size_t)nwaves + nw + (kLpRejMax + 1) / 2 + 2;
 }
 
 // (value, index) arg-max over the workgroup: largest value, lowest index among equal values.  Every thread gets the
@@ -113,15 +113,11 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
     const int nw = (m + 31) / 32;
 
     InvQr F;
-    F.R = n; F.RP = RP;
-    F.Qt = lds;
-    F.Wi = F.Qt + n * RP;
-    F.cv = F.Wi + n * RP;
-    F.ab = F.cv + n;
-    double *rb = F.ab + n;       // phase 1: residual direction r; phase 2: x
-    double *tb = rb + n;
-    double *yb = tb + n;
-    double *ctl_d = yb + n;      // [4]
+    invqr_bind(F, lds, n, RP);
+    double *rb = lds + invqr_lds_doubles(n, RP);   // phase 1: residual direction r; phase 2: x
+    double *tb = rb + n + kVecPad;
+    double *yb = tb + n + kVecPad;
+    double *ctl_d = yb + n + kVecPad;   // [4]
     int *ctl = reinterpret_cast<int *>(ctl_d + 4);   // [8]
     double *slots_v = ctl_d + 8;                     // [2][nwaves]
     int *slots_i = reinterpret_cast<int *>(slots_v + 2 * nwaves);   // [2][nwaves] (int)
@@ -137,12 +133,13 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
     const double rv = P.relax_val;
 
     // ---------------- initial state: Qt = I, cv = -f, empty working set
-    for (int e = tid; e < n * RP; e += T) {
-        F.Qt[e] = ((e / RP) == (e % RP)) ? 1.0 : 0.0;
-        F.Wi[e] = 0.0;
-    }
+    for (int e = tid; e < invqr_lds_doubles(n, RP) + 3 * (n + kVecPad); e += T) lds[e] = 0.0;   // Q, Wi, padded vectors
     for (int e = tid; e < nw; e += T) { inW[e] = 0u; abits[e] = 0u; }
-    if (tid < n) F.cv[tid] = -f[tid];
+    __syncthreads();
+    if (tid < n) {
+        F.Q[tid * RP + tid] = 1.0;
+        F.cv[tid] = -f[tid];
+    }
     __syncthreads();
 
     int k = 0, status = kStatusOptimal, outer = 0, inner = 0, piv = 0, flip = 0;
@@ -161,11 +158,7 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
             const double cl = (lane >= k && lane < n) ? F.cv[lane] : 0.0;
             const double rn = sqrt(wsum(cl * cl));
             const int done = (k >= n || k >= m || !(rn > 1e-13 * fnorm)) ? 1 : 0;
-            if (!done && lane < n) {
-                double ri = 0.0;
-                for (int l = k; l < n; ++l) ri = fma(F.Qt[l * RP + lane], F.cv[l], ri);
-                rb[lane] = ri;
-            }
+            if (!done && lane < n) rb[lane] = dotu(F.Q + lane * RP + k, F.cv + k, n - k);   // r = Qt'[0; cv[k:]]
             if (lane == 0) { ctl[0] = done; ctl[1] = 0; }
         }
         __syncthreads();
@@ -258,17 +251,9 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
             if (lane < k) bw = b[Wl] + (Wl == rx ? rv : 0.0);
             if (lane < n) F.ab[lane] = bw;
             wave_sync_lds();
-            if (lane < k) {
-                double s = 0.0;
-                for (int i = 0; i <= lane; ++i) s = fma(F.Wi[i * RP + lane], F.ab[i], s);
-                tb[lane] = s;
-            }
+            if (lane < n) tb[lane] = (lane < k) ? dots(F.Wi + lane, RP, F.ab, k) : 0.0;   // Wi' b_W (column `lane` of Wi)
             wave_sync_lds();
-            if (lane < n) {
-                double s = 0.0;
-                for (int l = 0; l < k; ++l) s = fma(F.Qt[l * RP + lane], tb[l], s);
-                rb[lane] = s;
-            }
+            if (lane < n) rb[lane] = dotu(F.Q + lane * RP, tb, k);                         // Qt[:k]' (Wi' b_W)
         }
         __syncthreads();
         double best = -1.0;
@@ -300,8 +285,7 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
                 if (lane < n) F.ab[lane] = t.qi;
                 wave_sync_lds();
                 double dl = 0.0;
-                if (lane < k)
-                    for (int c = lane; c < k; ++c) dl = fma(F.Wi[lane * RP + c], F.ab[c], dl);
+                if (lane < k) dl = dotu(F.Wi + lane * RP, F.ab, k);
                 const double zl = fmax(qr_coeff(F, k), 0.0);
                 const double dmax = wmax(lane < k ? fabs(dl) : 0.0);
                 const bool cand = (lane < k) && (dl > 1e-12 * fmax(1.0, dmax));

@@ -62,9 +62,7 @@ template <bool SHARED>
 int launch_solve(int mt, const SolveParams &P, int nwaves, size_t lds_bytes, long long nwg, hipStream_t st)
 {
     switch (mt) {
-    case 1: return launch_solve_mt<1, SHARED>(P, nwaves, lds_bytes, nwg, st);
     case 2: return launch_solve_mt<2, SHARED>(P, nwaves, lds_bytes, nwg, st);
-    case 3: return launch_solve_mt<3, SHARED>(P, nwaves, lds_bytes, nwg, st);
     case 4: return launch_solve_mt<4, SHARED>(P, nwaves, lds_bytes, nwg, st);
     case 6: return launch_solve_mt<6, SHARED>(P, nwaves, lds_bytes, nwg, st);
     case 8: return launch_solve_mt<8, SHARED>(P, nwaves, lds_bytes, nwg, st);
@@ -91,18 +89,19 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     P.n = n; P.m = m; P.p = p;
     P.RP = R | 1;
     P.L = ws_layout(n, m, p);
-    P.wave_doubles = wave_lds_doubles(n, m, P.RP);
+    P.wave_doubles = wave_lds_doubles(n, p, P.RP);
     const int mt = P.L.mp / 64;
-    const size_t shared_bytes = shared ? (size_t)(n + 1 + p) * P.L.mp * 8 : 0;
+    const size_t shared_bytes = shared ? shared_lds(n, P.L).total * 8 : 0;
     const size_t wave_bytes = (size_t)P.wave_doubles * 8;
     if (shared_bytes + 16 + wave_bytes > kLdsBytes)
         return fail(PYMPC_ERR_UNSUPPORTED, "QP %dx%d (p=%d) does not fit the 160 KiB LDS (%zu + %zu B)", n, m, p,
                     shared_bytes, wave_bytes);
     int nwaves = (int)((kLdsBytes - shared_bytes - 16) / wave_bytes);
     // without a staged matrix keep workgroups small so several fit a CU and balance at wave granularity
-    const int max_waves = mt <= 8 ? 8 : 4;   // = solve_max_waves<MT>() (launch bounds of the kernel)
+    const int max_waves = mt <= 8 ? 12 : 4;   // = solve_max_waves<MT>() (launch bounds of the kernel)
     const int cap = shared ? max_waves : 4;
     if (nwaves > cap) nwaves = cap;
+    if (shared && nwaves > 4) nwaves &= ~3;   // a multiple of the 4 SIMDs
     if ((long long)nwaves > P.B) nwaves = (int)P.B;
     if (nwaves < 1) nwaves = 1;
     const size_t lds_bytes = shared_bytes + 16 + wave_bytes * nwaves;

@@ -10,8 +10,8 @@
 //   u0  [n], Ku [n x p]   unconstrained minimiser u_unc(x) = u0 + Ku x = -Huu^-1 f(x)
 //   Huu [n x n], Hux [n x p], fu [n], Hxx [p x p], fx [p], g [1]   (objective, pnnls.py:234 + parametric_programs.py:177)
 //
-// Columns are padded to mp = 64 * MT (MT = columns per lane) so that every lane of a wavefront owns MT
-// columns; pad columns have Mt = 0, Gm = 0, m0 = 1 (their dual w = -1 is never selected).
+// Columns are padded to mp = 64 * MT (MT = columns per lane, even) so that every lane of a wavefront owns MT
+// columns (MT / 2 pairs of adjacent columns: lane l owns 128 h + 2 l and 128 h + 2 l + 1, h = 0 .. MT/2 - 1); pad columns have Mt = 0, Gm = 0, m0 = 1 (their dual w = -1 is never selected).
 // Mt, m0, Gm are contiguous so the shared-matrix kernel stages them into LDS with one linear copy.
 #pragma once
 #include <stddef.h>
@@ -31,7 +31,7 @@ constexpr int kMMax = 64 * kMTMax;
 __host__ __device__ inline int mt_bucket(int m)
 {
     const int need = (m + 63) / 64;
-    const int buckets[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    const int buckets[] = {2, 4, 6, 8, 12, 16, 24, 32};   // even: a lane owns PAIRS of adjacent columns (16-byte LDS reads)
     for (int b : buckets)
         if (need <= b) return b;
     return 0;

@@ -43,7 +43,7 @@ def algorithmic_flops(n, m, p, outer, inner):
 
 
 def executed_flops(n, m, p, outer, inner):
-    """Flops this kernel actually issues: it sweeps the UNtransformed matrix (2(n+1)m per outer iteration) and
+    """Flops this kernel's formulation needs: it sweeps the UNtransformed matrix (2(n+1)m per outer iteration) and
     updates a small Q / R^-1 pair (~6 R^2) instead of applying each reflector to every column."""
     R = n + 1
     k = outer.astype(np.float64)
@@ -165,11 +165,13 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         achieved = F.sum() / (kern_ms * 1e-3) / 1e12
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate passes,
+        # same command; see profiles/pmc_traffic.json for the raw counters and the gfx950 FETCH_SIZE caveat)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and B == 1000000:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("s%02d" % int(round(args.scale * 10)), {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -185,12 +187,14 @@ def main():
                        "mean_outer_iterations": float(iters[:, 0].mean()), "max_outer_iterations": int(iters[:, 0].max())},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "qp_solve_kernel<6,true>", "kernel_ms": kern_ms,
+                         "kernel": "qp_solve_kernel<%d,true>" % (2 * ((m + 127) // 128)), "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": float(F.sum()), "executed_flops_per_launch": float(Fx.sum()),
                          "executed_tflops": Fx.sum() / (kern_ms * 1e-3) / 1e12,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_algorithmic_gbs": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_gbs": PEAK_HBM_GBS,
-                         "note": "SURVEY 8(d): the NNLS kernels are bound by the fp64 vector ALU (+LDS), not HBM or MFMA"},
+                         "note": "SURVEY 8(d): the NNLS kernel is bound by fp64 vector-ALU issue (+LDS), not by HBM or MFMA; "
+                                 "achieved = algorithmic Lawson-Hanson flops (from the kernel's iteration counters) / kernel time; "
+                                 "peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz"},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(model, x_max, args.scale)

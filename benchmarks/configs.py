@@ -106,6 +106,7 @@ def c3():
         it = res.numpy('iters')
         t_batch = gpu_time(lambda: hip_lp.linear_program_batch(fd, Ad, bd, relax_idx=rx, relax_val=1., want_argmin=False,
                                                                want_mult=False, want_active=False))
+        Polyhedron(A.copy(), b.copy()).minimal_facets(); Polyhedron(A.copy(), b.copy()).radius      # warm-up (first launch of a shape)
         t0 = time.perf_counter(); P = Polyhedron(A.copy(), b.copy()); mf = P.minimal_facets(); t_mf = time.perf_counter() - t0
         t0 = time.perf_counter(); r = P.radius; t_ch = time.perf_counter() - t0
         piv = it[:, 2].astype(float) + it[:, 0]

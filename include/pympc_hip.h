@@ -165,12 +165,15 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
  * Table: region r owns rows row_ptr[r] .. row_ptr[r+1]-1 of A [total_rows x p], b [total_rows]
  * (total_rows = row_ptr[nreg], passed by the host so that nothing is read back); laws ux [nreg x nu x p],
  * u0 [nreg x nu] (first nu rows of the region's law), Vxx [nreg x p x p], Vx [nreg x p], V0 [nreg].
+ * box [nreg x 2 p] (p lower bounds, then p upper bounds; may be NULL): per region an axis-aligned box that contains
+ * every point its row test can accept; regions whose box holds none of a wavefront's points are skipped.  It only
+ * prunes: the result is the reference's first-hit region whatever the boxes are, as long as they are not too small.
  * Outputs: idx [B] int32 (-1 when uncovered), u [B x nu] (NaN when uncovered), V [B] (NaN when uncovered).
  * ------------------------------------------------------------------------------------------------- */
 int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
                          const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
-                         const double *Vx, const double *V0, const double *X, int64_t B, double tol, int32_t *idx,
-                         double *u, double *V, void *stream);
+                         const double *Vx, const double *V0, const double *box, const double *X, int64_t B, double tol,
+                         int32_t *idx, double *u, double *V, void *stream);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,48 @@ __device__ __forceinline__ void block_argmax(double &val, int &idx, double *slot
     val = bv; idx = bi;
 }
 
+constexpr int kLpJU = 4;   // rows of A per thread whose loads are in flight together
+
+// acc[q] += a_j . r for the rows j = min(jb + q T, m - 1), q < kLpJU (At is [n x m]: consecutive threads read
+// consecutive doubles).  NT = n when n <= 8 (all n kLpJU loads of a thread issued before the first FMA), 0 = generic n
+// (two columns of At at a time).  The compiler does not pipeline these loads by itself: with a plain loop a sweep costs
+// one L2 round trip per (row, column).
+template <int NT>
+__device__ __forceinline__ void lp_rowdots(const double *__restrict__ At, int m, int n, const double *rb, int jb, int T,
+                                           double (&acc)[kLpJU])
+{
+    size_t jq[kLpJU];
+#pragma unroll
+    for (int q = 0; q < kLpJU; ++q) jq[q] = (size_t)min(jb + q * T, m - 1);
+    if (NT > 0) {
+        double a[NT > 0 ? NT : 1][kLpJU];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int q = 0; q < kLpJU; ++q) a[i][q] = At[(size_t)i * m + jq[q]];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const double ri = rb[i];
+#pragma unroll
+            for (int q = 0; q < kLpJU; ++q) acc[q] = fma(a[i][q], ri, acc[q]);
+        }
+    } else {
+        for (int i = 0; i < n; i += 2) {
+            const int i1 = min(i + 1, n - 1);
+            const double r0 = rb[i], r1 = (i + 1 < n) ? rb[i1] : 0.0;
+            double a0[kLpJU], a1[kLpJU];
+#pragma unroll
+            for (int q = 0; q < kLpJU; ++q) {
+                a0[q] = At[(size_t)i * m + jq[q]];
+                a1[q] = At[(size_t)i1 * m + jq[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < kLpJU; ++q) acc[q] = fma(a1[q], r1, fma(a0[q], r0, acc[q]));
+        }
+    }
+}
+
+template <int NT>
 __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
 {
     extern __shared__ double lds[];
@@ -169,13 +211,18 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
             const int nrej = ctl[1];
             double best = -1.0;
             int bj = 0x7fffffff;
-            for (int j = tid; j < m; j += T) {
-                if ((inW[j >> 5] >> (j & 31)) & 1u) continue;
-                double w = 0.0;
-                for (int i = 0; i < n; ++i) w = fma(At[(size_t)i * m + j], rb[i], w);
-                for (int q = 0; q < nrej; ++q)
-                    if (rej[q] == j) w = 0.0;
-                if (w > best) { best = w; bj = j; }
+            for (int jb = tid; jb < m; jb += T * kLpJU) {
+                double acc[kLpJU] = {0.0, 0.0, 0.0, 0.0};
+                lp_rowdots<NT>(At, m, n, rb, jb, T, acc);
+#pragma unroll
+                for (int q = 0; q < kLpJU; ++q) {
+                    const int j = jb + q * T;
+                    if (j >= m || ((inW[j >> 5] >> (j & 31)) & 1u)) continue;
+                    double w = acc[q];
+                    for (int c = 0; c < nrej; ++c)
+                        if (rej[c] == j) w = 0.0;
+                    if (w > best) { best = w; bj = j; }
+                }
             }
             block_argmax(best, bj, slots_v + flip * nwaves, slots_i + flip * nwaves, nwaves);
             flip ^= 1;
@@ -258,14 +305,24 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
         __syncthreads();
         double best = -1.0;
         int be = 0x7fffffff;
-        for (int j = tid; j < m; j += T) {
-            if ((inW[j >> 5] >> (j & 31)) & 1u) continue;
-            const double bj = b[j] + (j == rx ? rv : 0.0);
-            double v = -bj;
-            for (int i = 0; i < n; ++i) v = fma(At[(size_t)i * m + j], rb[i], v);
-            if (v > 1e-9 * fmax(1.0, fabs(bj))) {
-                const double sc = v * ainv[j];
-                if (sc > best) { best = sc; be = j; }
+        for (int jb = tid; jb < m; jb += T * kLpJU) {
+            double acc[kLpJU], bq[kLpJU];
+#pragma unroll
+            for (int q = 0; q < kLpJU; ++q) {
+                const int j = min(jb + q * T, m - 1);
+                bq[q] = b[j] + (j == rx ? rv : 0.0);
+                acc[q] = -bq[q];
+            }
+            lp_rowdots<NT>(At, m, n, rb, jb, T, acc);
+#pragma unroll
+            for (int q = 0; q < kLpJU; ++q) {
+                const int j = jb + q * T;
+                if (j >= m || ((inW[j >> 5] >> (j & 31)) & 1u)) continue;
+                const double v = acc[q];
+                if (v > 1e-9 * fmax(1.0, fabs(bq[q]))) {
+                    const double sc = v * ainv[j];
+                    if (sc > best) { best = sc; be = j; }
+                }
             }
         }
         block_argmax(best, be, slots_v + flip * nwaves, slots_i + flip * nwaves, nwaves);

@@ -11,6 +11,9 @@
 // A region is abandoned as soon as every still-searching lane of the wave has violated one of its rows, and the
 // scan stops when every lane has found its region; neighbouring grid points mostly share regions, so the wave
 // rarely does more rows than its slowest lane needs.
+// Optional pruning that keeps the first-hit semantics exactly: `box` holds, per region, an axis-aligned box that
+// contains every point the row test can accept (the host computes it with 2 p LPs over {A x <= b + tol}, inflated);
+// a region whose box contains none of the wave's still-searching points is skipped without touching its rows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,10 +21,11 @@
 namespace pympc {
 
 struct PlParams {
-    int nreg, p, nu, total_rows, table_in_lds;
+    int nreg, p, nu, total_rows, table_in_lds, box_in_lds;
     const double *A, *b;
     const int32_t *row_ptr;
     const double *ux, *u0, *Vxx, *Vx, *V0;
+    const double *box;   // [nreg x 2 p] (lower bounds, then upper bounds) or null
     const double *X;
     long long B;
     double tol;
@@ -43,6 +47,13 @@ __global__ void point_location_kernel(PlParams P)
         At = lds;
         bt = lds + na;
     }
+    const double *box = P.box;
+    if (P.box && P.box_in_lds) {
+        double *bl = lds + (P.table_in_lds ? P.total_rows * (PD + 1) : 0);
+        for (int e = tid; e < P.nreg * 2 * PD; e += blockDim.x) bl[e] = P.box[e];
+        __syncthreads();
+        box = bl;
+    }
     const double nanv = __builtin_nan("");
     const long long stride = (long long)gridDim.x * blockDim.x;
     // every lane of a wave runs the same number of grid-stride rounds (wave-uniform loop bound)
@@ -58,6 +69,12 @@ __global__ void point_location_kernel(PlParams P)
             const bool searching = valid && found < 0;
             if (__ballot(searching) == 0ull) break;
             bool inside = searching;
+            if (box) {
+                const double *lo = box + (size_t)r * 2 * PD, *hi = lo + PD;
+#pragma unroll
+                for (int q = 0; q < PD; ++q) inside = inside && (x[q] >= lo[q]) && (x[q] <= hi[q]);
+                if (__ballot(inside) == 0ull) continue;
+            }
             const int i1 = P.row_ptr[r + 1];
             for (int i = P.row_ptr[r]; i < i1; ++i) {
                 double s = -bt[i];

@@ -74,6 +74,14 @@ int launch_solve(int mt, const SolveParams &P, int nwaves, size_t lds_bytes, lon
     return fail(PYMPC_ERR_UNSUPPORTED, "no kernel for %d columns per lane", mt);
 }
 
+// threads of the per-problem prepare workgroup: one per constraint row (up to 256), at least one wave
+int prep_threads(int n, int m)
+{
+    int t = ((m + 63) / 64) * 64;
+    if (n * n >= 1024 && t < 256) t = 256;
+    return t > 256 ? 256 : t;
+}
+
 int check_shape(int n, int m, int p)
 {
     if (n < 1 || m < 1 || p < 0) return fail(PYMPC_ERR_ARG, "bad shape n=%d m=%d p=%d", n, m, p);
@@ -123,7 +131,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
 
 extern "C" {
 
-int pympc_hip_abi_version(void) { return 2; }
+int pympc_hip_abi_version(void) { return 3; }
 
 const char *pympc_hip_last_error(void) { return g_err; }
 
@@ -203,7 +211,7 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
     const size_t lds = (size_t)3 * n * (n + 1) * 8;
     if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
-    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(n * n >= 1024 ? 256 : 64), lds, (hipStream_t)stream, Q);
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(prep_threads(n, m)), lds, (hipStream_t)stream, Q);
     if (int rc = check_launch("qp_prepare_kernel")) return rc;
     SolveParams P;
     memset(&P, 0, sizeof(P));
@@ -247,7 +255,7 @@ int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, co
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
     const size_t lds = (size_t)3 * n * (n + 1) * 8;
     if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
-    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(n * n >= 1024 ? 256 : 64), lds, (hipStream_t)stream, Q);
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(prep_threads(n, m)), lds, (hipStream_t)stream, Q);
     if (int rc = check_launch("qp_prepare_kernel")) return rc;
     SolveParams P;
     memset(&P, 0, sizeof(P));
@@ -357,15 +365,24 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
     if (threads > 512) threads = 512;
     const size_t lds_bytes = lp_lds_doubles(n, m, P.RP, threads / 64) * 8;
     if (lds_bytes > kLdsBytes) return fail(PYMPC_ERR_UNSUPPORTED, "LP %dx%d does not fit the 160 KiB LDS", n, m);
-    if (int rc = allow_lds(lp_solve_kernel, lds_bytes)) return rc;
-    hipLaunchKernelGGL(lp_solve_kernel, dim3((unsigned)B), dim3(threads), lds_bytes, st, P);
+#define PYMPC_LP_CASE(NT)                                                                            \
+    case NT: {                                                                                       \
+        if (int rc = allow_lds(lp_solve_kernel<NT>, lds_bytes)) return rc;                           \
+        hipLaunchKernelGGL(lp_solve_kernel<NT>, dim3((unsigned)B), dim3(threads), lds_bytes, st, P); \
+        break;                                                                                       \
+    }
+    switch (n <= 8 ? n : 0) {
+        PYMPC_LP_CASE(0) PYMPC_LP_CASE(1) PYMPC_LP_CASE(2) PYMPC_LP_CASE(3) PYMPC_LP_CASE(4)
+        PYMPC_LP_CASE(5) PYMPC_LP_CASE(6) PYMPC_LP_CASE(7) PYMPC_LP_CASE(8)
+    }
+#undef PYMPC_LP_CASE
     return check_launch("lp_solve_kernel");
 }
 
 int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
                          const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
-                         const double *Vx, const double *V0, const double *X, int64_t B, double tol, int32_t *idx,
-                         double *u, double *V, void *stream)
+                         const double *Vx, const double *V0, const double *box, const double *X, int64_t B, double tol,
+                         int32_t *idx, double *u, double *V, void *stream)
 {
     if (nreg < 0 || total_rows < 0 || p < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_point_location: bad shape");
     if (p > 8) return fail(PYMPC_ERR_UNSUPPORTED, "point location supports up to 8 parameters, got %d", p);
@@ -377,10 +394,15 @@ int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *
     memset(&P, 0, sizeof(P));
     P.nreg = nreg; P.p = p; P.nu = nu; P.total_rows = total_rows;
     P.A = A; P.b = b; P.row_ptr = row_ptr; P.ux = ux; P.u0 = u0; P.Vxx = Vxx; P.Vx = Vx; P.V0 = V0;
-    P.X = X; P.B = B; P.tol = tol; P.idx = idx; P.u = u; P.V = V;
+    P.box = box; P.X = X; P.B = B; P.tol = tol; P.idx = idx; P.u = u; P.V = V;
     const size_t table_bytes = (size_t)total_rows * (p + 1) * 8;
-    P.table_in_lds = table_bytes <= 150 * 1024;
-    const size_t lds = P.table_in_lds ? table_bytes : 0;
+    // with pruning boxes a wave touches the rows of a few regions only: leave a large table in L2 / L1 and keep the
+    // LDS for occupancy (the boxes are 16 p bytes per region)
+    P.table_in_lds = table_bytes <= (box ? 16 * 1024 : 150 * 1024);
+    size_t lds = P.table_in_lds ? table_bytes : 0;
+    const size_t box_bytes = box ? (size_t)nreg * 2 * p * 8 : 0;
+    P.box_in_lds = box && lds + box_bytes <= 150 * 1024;
+    if (P.box_in_lds) lds += box_bytes;
     const int threads = 256;
     long long nwg = (B + threads - 1) / threads;
     const long long cap = 256LL * (lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 8)) * 4;   // grid-stride beyond a few waves of workgroups

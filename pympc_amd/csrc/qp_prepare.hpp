@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "invqr_wave.hpp"
 #include "ws_layout.hpp"
 
 namespace pympc {
@@ -98,28 +99,18 @@ __global__ void qp_prepare_kernel(PrepParams P)
         Hi[i * ld + j] = s;
     }
     __syncthreads();
-    // rows of A: M = A L^-T (pnnls.py:213), T = A H^-1, m0, Gm (pnnls.py:214 split into its affine parts)
+    // rows of A: M = A L^-T (pnnls.py:213), T = A H^-1, m0, Gm (pnnls.py:214 split into its affine parts).
+    // One row per thread; every short sum goes through dot8 (loads issued eight at a time: these loops have run-time
+    // bounds and the compiler would otherwise pay one memory round trip per term).  H^-1 is exactly symmetric (both
+    // triangles are the same sums of the same products), so T_j = H^-1 a_j reads ROWS of Hi (unit stride).
     for (int j = tid; j < mp; j += nt) {
         if (j < m) {
             const double *aj = A + (size_t)j * n;
-            for (int i = 0; i < n; ++i) {
-                double s = 0.0;
-                for (int q = 0; q <= i; ++q) s = fma(aj[q], Li[i * ld + q], s);
-                ws[L.Mt + (size_t)i * mp + j] = s;
-            }
-            double mj = b[j];
-            for (int i = 0; i < n; ++i) {
-                double s = 0.0;
-                for (int q = 0; q < n; ++q) s = fma(aj[q], Hi[q * ld + i], s);
-                ws[L.T + (size_t)j * n + i] = s;
-                mj = fma(s, fu[i], mj);
-            }
-            ws[L.m0 + j] = mj;
-            for (int q = 0; q < p; ++q) {
-                double s = -Ax[(size_t)j * p + q];
-                for (int i = 0; i < n; ++i) s = fma(ws[L.T + (size_t)j * n + i], Hux[i * p + q], s);
-                ws[L.Gm + (size_t)q * mp + j] = s;
-            }
+            double *Tj = ws + L.T + (size_t)j * n;
+            for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = dot8(aj, 1, Li + i * ld, 1, 0, i + 1);
+            for (int i = 0; i < n; ++i) Tj[i] = dot8(aj, 1, Hi + i * ld, 1, 0, n);
+            ws[L.m0 + j] = dot8(Tj, 1, fu, 1, 0, n, b[j]);
+            for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = dot8(Tj, 1, Hux + q, p, 0, n, -Ax[(size_t)j * p + q]);
         } else {
             for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = 0.0;
             ws[L.m0 + j] = 1.0;

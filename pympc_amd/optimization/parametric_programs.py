@@ -247,12 +247,50 @@ class ExplicitSolution(object):
                  u0=np.array([cr._u['0'][:nu] for cr in crs]).reshape(len(crs), nu),
                  Vxx=np.array([cr._V['xx'] for cr in crs]), Vx=np.array([cr._V['x'] for cr in crs]),
                  V0=np.array([cr._V['0'] for cr in crs], dtype=np.float64))
-        t['dev'] = {k: _hip.to_device(t[k]) for k in ('A', 'b', 'ux', 'u0', 'Vxx', 'Vx', 'V0')}
+        t['box'] = self._bounding_boxes(t, tol=1.e-7)
+        t['dev'] = {k: _hip.to_device(t[k]) for k in ('A', 'b', 'ux', 'u0', 'Vxx', 'Vx', 'V0', 'box')}
         t['dev']['row_ptr'] = _hip.to_device(row_ptr, dtype=torch.int32)
         self._table = t
         return t
 
-    def locate(self, X, nu=None, tol=1.e-7):
+    @staticmethod
+    def _bounding_boxes(t, tol):
+        """
+        [nreg x 2p] axis-aligned boxes (lower bounds, then upper bounds) that contain every point the kernel's row test
+        max(A x - b) <= tol can accept in a region: 2 p LPs per region over {A x <= b + tol}, one batched launch for
+        the whole table, inflated by 1e-9 (LP accuracy and the rounding of the row test are orders below that).
+        Unbounded or empty directions get an infinite bound, i.e. no pruning.  The boxes only let the kernel skip
+        regions; the first-hit semantics of parametric_programs.py:442-463 is untouched.
+        """
+        from .solvers import hip_lp
+        nreg, p, rp = t['nreg'], t['p'], t['row_ptr']
+        box = np.empty((nreg, 2 * p))
+        box[:, :p] = -np.inf
+        box[:, p:] = np.inf
+        if nreg == 0:
+            return box
+        rows = np.diff(rp)
+        mmax = int(rows.max())
+        n_lp, m_lp = hip_lp._hip.lp_limits()
+        if mmax == 0 or p > n_lp or mmax > m_lp:
+            return box
+        A = np.zeros((nreg, mmax, p)); b = np.ones((nreg, mmax))          # pad rows 0 x <= 1 never bind
+        for r in range(nreg):
+            A[r, :rows[r]] = t['A'][rp[r]:rp[r + 1]]
+            b[r, :rows[r]] = t['b'][rp[r]:rp[r + 1]] + tol + 1.e-9
+        f = np.vstack((np.eye(p), -np.eye(p)))                             # min x_i, then min -x_i
+        res = hip_lp.linear_program_batch(np.tile(f, (nreg, 1)), np.repeat(A, 2 * p, axis=0), np.repeat(b, 2 * p, axis=0),
+                                          want_argmin=False, want_mult=False, want_active=False)
+        st = res.numpy('status').reshape(nreg, 2 * p)
+        v = res.numpy('min').reshape(nreg, 2 * p)
+        lo = np.where(st[:, :p] == 0, v[:, :p], -np.inf)
+        hi = np.where(st[:, p:] == 0, -v[:, p:], np.inf)
+        pad = 1.e-9
+        box[:, :p] = lo - pad * (1. + np.abs(lo))
+        box[:, p:] = hi + pad * (1. + np.abs(hi))
+        return box
+
+    def locate(self, X, nu=None, tol=1.e-7, use_boxes=True):
         """Batched look-up: X [B x p] -> device tensors (idx int32 [B], u [B x nu], V [B]); no synchronisation."""
         lib = _hip.load_library()
         t = self.table(nu)
@@ -267,7 +305,8 @@ class ExplicitSolution(object):
         d = t['dev']
         _hip.check(lib.pympc_point_location(t['nreg'], t['total_rows'], t['p'], t['nu'], _hip.ptr(d['A']), _hip.ptr(d['b']),
                                             _hip.ptr(d['row_ptr']), _hip.ptr(d['ux']), _hip.ptr(d['u0']), _hip.ptr(d['Vxx']),
-                                            _hip.ptr(d['Vx']), _hip.ptr(d['V0']), _hip.ptr(X), B, float(tol),
+                                            _hip.ptr(d['Vx']), _hip.ptr(d['V0']),
+                                            _hip.ptr(d['box']) if (use_boxes and tol <= 1.e-7) else None, _hip.ptr(X), B, float(tol),
                                             _hip.ptr(idx), _hip.ptr(u), _hip.ptr(V), _hip.stream_ptr()))
         return idx, u, V
 

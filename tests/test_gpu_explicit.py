@@ -142,6 +142,13 @@ def test_point_location_vs_oracle(nb, oracle):
         unc = ok & (ridx < 0)
         assert np.all(np.isnan(V[unc])) and np.all(np.isnan(u[unc]))
     assert (ridx >= 0).mean() > .3 and (ridx < 0).sum() > 1000
+    # the bounding-box pruning only skips work: identical outputs with and without it, ties included
+    a = es.locate(X, nu=1, use_boxes=True); c = es.locate(X, nu=1, use_boxes=False)
+    assert np.array_equal(a[0].cpu().numpy(), c[0].cpu().numpy())
+    assert np.array_equal(a[1].cpu().numpy(), c[1].cpu().numpy(), equal_nan=True)
+    assert np.array_equal(a[2].cpu().numpy(), c[2].cpu().numpy(), equal_nan=True)
+    box = es.table(1)['box']
+    assert np.isfinite(box).all() and np.all(box[:, :2] < box[:, 2:])
     # scalar look-ups
     i = int(np.where(ridx >= 0)[0][0])
     assert es.get_critical_region(X[i]) is crs[ridx[i]]

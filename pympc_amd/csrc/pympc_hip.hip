@@ -74,12 +74,19 @@ int launch_solve(int mt, const SolveParams &P, int nwaves, size_t lds_bytes, lon
     return fail(PYMPC_ERR_UNSUPPORTED, "no kernel for %d columns per lane", mt);
 }
 
-// threads of the per-problem prepare workgroup: one per constraint row (up to 256), at least one wave
-int prep_threads(int n, int m)
+// Launch geometry of the per-problem prepare workgroup: one thread per constraint row of a tile (up to 256 rows,
+// fewer when two row tiles of that size would not fit beside the factor matrices in ~96 KiB of LDS).
+struct PrepGeom { int threads, tile_rows; size_t lds_bytes; };
+PrepGeom prep_geom(int n, int m, int p)
 {
-    int t = ((m + 63) / 64) * 64;
-    if (n * n >= 1024 && t < 256) t = 256;
-    return t > 256 ? 256 : t;
+    PrepGeom G;
+    int tr = ((m + 63) / 64) * 64;
+    if (tr > 256) tr = 256;
+    while (tr > 64 && prep_lds_doubles(n, p, tr) * 8 > 96 * 1024) tr -= 64;
+    G.tile_rows = tr;
+    G.threads = (n * n >= 1024 && tr < 256) ? 256 : tr;
+    G.lds_bytes = prep_lds_doubles(n, p, tr) * 8;
+    return G;
 }
 
 int check_shape(int n, int m, int p)
@@ -160,9 +167,10 @@ int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux
     P.L = ws_layout(n, m, p);
     P.H = Huu; P.Hux = Hux; P.Hxx = Hxx; P.fu = fu; P.fx = fx; P.gs = nullptr; P.g_host = g;
     P.A = Au; P.Ax = Ax; P.b = b; P.ws = ws; P.ws_status = ws_status;
-    const size_t lds = (size_t)3 * n * (n + 1) * 8;
-    if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
-    hipLaunchKernelGGL(qp_prepare_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, P);
+    const PrepGeom G = prep_geom(n, m, p);
+    P.tile_rows = G.tile_rows;
+    if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3(1), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, P);
     return check_launch("qp_prepare_kernel");
 }
 
@@ -209,9 +217,10 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
     Q.b = b; Q.b_stride = m;
     Q.g_host = 0.0;
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
-    const size_t lds = (size_t)3 * n * (n + 1) * 8;
-    if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
-    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(prep_threads(n, m)), lds, (hipStream_t)stream, Q);
+    const PrepGeom G = prep_geom(n, m, Q.p);
+    Q.tile_rows = G.tile_rows;
+    if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);
     if (int rc = check_launch("qp_prepare_kernel")) return rc;
     SolveParams P;
     memset(&P, 0, sizeof(P));
@@ -253,9 +262,10 @@ int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, co
     Q.Ax = Ax; Q.ax_stride = (long long)m * p;
     Q.b = b; Q.b_stride = m;
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
-    const size_t lds = (size_t)3 * n * (n + 1) * 8;
-    if (int rc = allow_lds(qp_prepare_kernel, lds)) return rc;
-    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(prep_threads(n, m)), lds, (hipStream_t)stream, Q);
+    const PrepGeom G = prep_geom(n, m, Q.p);
+    Q.tile_rows = G.tile_rows;
+    if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);
     if (int rc = check_launch("qp_prepare_kernel")) return rc;
     SolveParams P;
     memset(&P, 0, sizeof(P));

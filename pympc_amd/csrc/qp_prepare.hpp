@@ -29,7 +29,15 @@ struct PrepParams {
     const double *b;   long long b_stride;    // [m]
     double *ws;        long long ws_stride;
     int32_t *ws_status;
+    int tile_rows;     // constraint rows staged in LDS at a time (= threads that work on rows)
 };
+
+// LDS doubles of the prepare kernel: three n x (n+1) matrices (L, L^-1, H^-1), fu and Hux, and two row tiles
+// (A rows in, T rows out) of tile_rows x (n | 1) doubles each: global memory is only touched with coalesced accesses
+__host__ __device__ inline size_t prep_lds_doubles(int n, int p, int tile_rows)
+{
+    return (size_t)3 * n * (n + 1) + n + (size_t)n * p + (size_t)2 * tile_rows * (n | 1) + 2;
+}
 
 __global__ void qp_prepare_kernel(PrepParams P)
 {
@@ -52,7 +60,8 @@ __global__ void qp_prepare_kernel(PrepParams P)
     double *Ls = lds;             // n x ld, lower Cholesky factor
     double *Li = Ls + n * ld;     // n x ld, L^-1
     double *Hi = Li + n * ld;     // n x ld, H^-1
-    __shared__ int notpd;
+    // flag in the dynamic block (a static __shared__ would shift the dynamic base off its 8-byte alignment)
+    int &notpd = *reinterpret_cast<int *>(lds + prep_lds_doubles(n, p, P.tile_rows) - 2);
     if (tid == 0) notpd = 0;
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e % n;
@@ -100,23 +109,41 @@ __global__ void qp_prepare_kernel(PrepParams P)
     }
     __syncthreads();
     // rows of A: M = A L^-T (pnnls.py:213), T = A H^-1, m0, Gm (pnnls.py:214 split into its affine parts).
-    // One row per thread; every short sum goes through dot8 (loads issued eight at a time: these loops have run-time
-    // bounds and the compiler would otherwise pay one memory round trip per term).  H^-1 is exactly symmetric (both
-    // triangles are the same sums of the same products), so T_j = H^-1 a_j reads ROWS of Hi (unit stride).
-    for (int j = tid; j < mp; j += nt) {
-        if (j < m) {
-            const double *aj = A + (size_t)j * n;
-            double *Tj = ws + L.T + (size_t)j * n;
-            for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = dot8(aj, 1, Li + i * ld, 1, 0, i + 1);
-            for (int i = 0; i < n; ++i) Tj[i] = dot8(aj, 1, Hi + i * ld, 1, 0, n);
-            ws[L.m0 + j] = dot8(Tj, 1, fu, 1, 0, n, b[j]);
-            for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = dot8(Tj, 1, Hux + q, p, 0, n, -Ax[(size_t)j * p + q]);
-        } else {
-            for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = 0.0;
-            ws[L.m0 + j] = 1.0;
-            for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = 0.0;
+    // Tiles of tile_rows rows: coalesced copy of the rows into LDS (pitch n | 1: conflict-free row-per-thread access),
+    // one row per thread, T tile written back coalesced.  Every short sum goes through dot8 (loads issued eight at a
+    // time).  H^-1 is exactly symmetric (both triangles are the same sums of the same products), so T_j = H^-1 a_j
+    // reads ROWS of Hi (unit stride).
+    const int np = n | 1, TR = P.tile_rows;
+    double *fus = Hi + n * ld;          // [n]
+    double *Hs = fus + n;               // [n x p]
+    double *As = Hs + n * p;            // [TR x np]
+    double *Ts = As + (size_t)TR * np;  // [TR x np]
+    for (int e = tid; e < n; e += nt) fus[e] = fu[e];
+    for (int e = tid; e < n * p; e += nt) Hs[e] = Hux[e];
+    for (int row0 = 0; row0 < mp; row0 += TR) {
+        const int rows = min(TR, m - row0);          // real rows in this tile (<= 0: only padding columns)
+        __syncthreads();
+        for (int e = tid; e < rows * n; e += nt) As[(e / n) * np + (e % n)] = A[(size_t)row0 * n + e];
+        __syncthreads();
+        const int j = row0 + tid;
+        if (tid < TR && j < mp) {
+            if (j < m) {
+                const double *aj = As + tid * np;
+                double *Tj = Ts + tid * np;
+                for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = dot8(aj, 1, Li + i * ld, 1, 0, i + 1);
+                for (int i = 0; i < n; ++i) Tj[i] = dot8(aj, 1, Hi + i * ld, 1, 0, n);
+                ws[L.m0 + j] = dot8(Tj, 1, fus, 1, 0, n, b[j]);
+                for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = dot8(Tj, 1, Hs + q, p, 0, n, -Ax[(size_t)j * p + q]);
+            } else {
+                for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = 0.0;
+                ws[L.m0 + j] = 1.0;
+                for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = 0.0;
+            }
         }
+        __syncthreads();
+        for (int e = tid; e < rows * n; e += nt) ws[L.T + (size_t)row0 * n + e] = Ts[(e / n) * np + (e % n)];
     }
+    __syncthreads();
     // unconstrained minimiser and copies of the objective blocks
     for (int i = tid; i < n; i += nt) {
         double s = 0.0;

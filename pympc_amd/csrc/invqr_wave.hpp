@@ -53,7 +53,8 @@ constexpr int kDppMirror = 0x140;      // row_mirror:      lane i <-> 15 - i ins
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+    // every lane has a valid source for these controls; bound_ctrl lets the compiler drop the copy into `old`
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
@@ -71,6 +72,20 @@ __device__ __forceinline__ double lane_f64(double v, int src)
 {
     const int s = __builtin_amdgcn_readfirstlane(src);
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), s), __builtin_amdgcn_readlane(__double2loint(v), s));
+}
+
+// IEEE max / min as ONE instruction: fmax() / fmin() are emitted with a canonicalising v_max x, x, x on each operand
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double min_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ double wsum(double v)
@@ -103,19 +118,19 @@ __device__ __forceinline__ void wsum3(double &a, double &b, double &c)
 }
 __device__ __forceinline__ double wmin(double v)
 {
-    v = fmin(v, dpp_f64<kDppXor1>(v));
-    v = fmin(v, dpp_f64<kDppXor2>(v));
-    v = fmin(v, dpp_f64<kDppHalfMirror>(v));
-    v = fmin(v, dpp_f64<kDppMirror>(v));
-    return fmin(fmin(lane_f64(v, 0), lane_f64(v, 16)), fmin(lane_f64(v, 32), lane_f64(v, 48)));
+    v = min_raw(v, dpp_f64<kDppXor1>(v));
+    v = min_raw(v, dpp_f64<kDppXor2>(v));
+    v = min_raw(v, dpp_f64<kDppHalfMirror>(v));
+    v = min_raw(v, dpp_f64<kDppMirror>(v));
+    return min_raw(min_raw(lane_f64(v, 0), lane_f64(v, 16)), min_raw(lane_f64(v, 32), lane_f64(v, 48)));
 }
 __device__ __forceinline__ double wmax(double v)
 {
-    v = fmax(v, dpp_f64<kDppXor1>(v));
-    v = fmax(v, dpp_f64<kDppXor2>(v));
-    v = fmax(v, dpp_f64<kDppHalfMirror>(v));
-    v = fmax(v, dpp_f64<kDppMirror>(v));
-    return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
+    v = max_raw(v, dpp_f64<kDppXor1>(v));
+    v = max_raw(v, dpp_f64<kDppXor2>(v));
+    v = max_raw(v, dpp_f64<kDppHalfMirror>(v));
+    v = max_raw(v, dpp_f64<kDppMirror>(v));
+    return max_raw(max_raw(lane_f64(v, 0), lane_f64(v, 16)), max_raw(lane_f64(v, 32), lane_f64(v, 48)));
 }
 __device__ __forceinline__ int wmin_int(int v)
 {

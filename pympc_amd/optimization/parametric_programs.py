@@ -134,8 +134,9 @@ class MultiParametricQuadraticProgram(object):
             cr = self.explicit_solve_given_point(x, guess, verbose)
             if cr is None:
                 continue
-            for i in cr.minimal_facets():
-                step = cr.facet_center(i) + step_size * cr.A[i]
+            facets = cr.minimal_facets()
+            for i, c in zip(facets, cr.facet_centers(facets)):   # one batched launch for all facet centres of the region
+                step = c + step_size * cr.A[i]
                 flipped = set(cr.active_set).symmetric_difference({i})
                 x_buffer.append((step, sorted(flipped)))
             crs_found.append(cr)
@@ -195,6 +196,40 @@ class CriticalRegion(object):
         facet = copy(P)
         facet.add_equality(facet.A[i:i + 1, :], facet.b[i:i + 1])
         return facet.center
+
+    def facet_centers(self, indices):
+        """
+        Chebyshev centres of several facets at once: the LPs of facet_center(i), i in indices, have one shape
+        (rows x p) and go out as ONE batched launch.  Returns a list of points (None where the LP has no optimum).
+        """
+        from ..geometry.polyhedron import nullspace_basis
+        from .solvers import hip_lp
+        P = self.polyhedron
+        indices = [int(i) for i in indices]
+        p = P.A.shape[1]
+        if p == 1 or P.C.shape[0] > 0 or len(indices) == 0:
+            return [self.facet_center(i) for i in indices]
+        A, b = P.A, P.b
+        As, bs, maps = [], [], []
+        for i in indices:                       # x = N n + R r on the hyperplane a_i x = b_i (polyhedron.py:468-503)
+            C = A[i:i + 1]
+            N = nullspace_basis(C)
+            R = nullspace_basis(N.T)
+            r = np.linalg.inv(C.dot(R)).dot(b[i:i + 1])
+            E = A.dot(N)
+            As.append(np.hstack((E, -np.linalg.norm(E, axis=1).reshape(-1, 1))))
+            bs.append(b - A.dot(R.dot(r)))
+            maps.append((N, R, r))
+        f = np.zeros((len(indices), p)); f[:, -1] = 1.
+        res = hip_lp.linear_program_batch(f, np.array(As), np.array(bs), want_mult=False, want_active=False)
+        st = res.numpy('status')
+        if np.any(st == 3):
+            raise RuntimeError('Maximum number of iterations reached.')
+        z = res.numpy('argmin')
+        out = []
+        for k, (N, R, r) in enumerate(maps):
+            out.append(None if st[k] != 0 else np.hstack((N, R)).dot(np.concatenate((z[k, :-1], r))))
+        return out
 
     def u(self, x):
         return self._u['x'].dot(x) + self._u['0']

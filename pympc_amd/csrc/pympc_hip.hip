@@ -106,8 +106,11 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     P.L = ws_layout(n, m, p);
     P.wave_doubles = wave_lds_doubles(n, p, P.RP);
     const int mt = P.L.mp / 64;
-    const size_t shared_bytes = shared ? shared_lds(n, P.L).total * 8 : 0;
     const size_t wave_bytes = (size_t)P.wave_doubles * 8;
+    // a matrix too large to be staged beside four problems stays in global memory (one workspace, ws_stride 0, read
+    // through L2 by every wave) instead of being refused
+    if (shared && shared_lds(n, P.L).total * 8 + 16 + 4 * wave_bytes > kLdsBytes) shared = false;
+    const size_t shared_bytes = shared ? shared_lds(n, P.L).total * 8 : 0;
     if (shared_bytes + 16 + wave_bytes > kLdsBytes)
         return fail(PYMPC_ERR_UNSUPPORTED, "QP %dx%d (p=%d) does not fit the 160 KiB LDS (%zu + %zu B)", n, m, p,
                     shared_bytes, wave_bytes);

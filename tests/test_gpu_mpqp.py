@@ -124,3 +124,26 @@ def test_full_size_properties():
     assert L.min() >= 0.0
     stat = U.dot(model["Huu"].T) + fx + L.dot(model["Au"])
     assert np.abs(stat).max() < 1e-7 * max(1.0, np.abs(L).max())
+
+
+@pytest.mark.parametrize("n,m,p", [(40, 800, 6), (63, 2048, 3), (5, 64, 2), (33, 129, 8)])
+def test_mpqp_shapes_beyond_the_lds_image(oracle, n, m, p):
+    """mpQPs whose constant matrix cannot be staged in LDS beside four problems (and the limits n = 63, m = 2048) run
+    through the same kernel with the matrix read from L2; results against the oracle's reference loop."""
+    from pympc_amd.optimization.solvers.hip import PreparedMpqp
+    rng = np.random.RandomState(n + m)
+    L = rng.randn(n, n); Huu = L.dot(L.T) + n * np.eye(n)
+    model = dict(Huu=Huu, Hux=rng.randn(n, p), Hxx=np.eye(p), fu=rng.randn(n), fx=rng.randn(p), g=np.asarray(.5),
+                 Au=rng.randn(m, n), Ax=rng.randn(m, p), b=np.abs(rng.randn(m)) * 3. + 1.)
+    X = rng.randn(24, p) * .7
+    prep = PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model["fx"], float(model["g"]),
+                        model["Au"], model["Ax"], model["b"])
+    res = prep.solve_batch(X)
+    ref = oracle.mpqp_solve_batch(model, X)
+    feas = ref["status"] == 0
+    assert np.array_equal(res.numpy("status") == 0, feas) and feas.sum() >= 1
+    assert np.allclose(res.numpy("argmin")[feas], ref["argmin"][feas], rtol=1e-6, atol=1e-6)
+    assert np.allclose(res.numpy("min")[feas], ref["min"][feas], rtol=1e-6, atol=1e-6)
+    lam = ref["multiplier_inequality"][feas]
+    edge = np.abs(lam - 1e-7) < 1e-9                       # multipliers sitting on the 1e-7 threshold
+    assert np.array_equal(res.active_mask()[feas][~edge], ref["active"][feas][~edge])

@@ -182,9 +182,10 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
                            int32_t *iters, void *stream)
 {
     if (int rc = check_shape(n, m, p)) return rc;
-    if (B < 0 || !ws || !status || (p > 0 && B > 0 && !X)) return fail(PYMPC_ERR_ARG, "pympc_mpqp_solve_batch: bad argument");
+    if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_mpqp_solve_batch: negative batch size");
     if (n_out < 0 || n_out > n) return fail(PYMPC_ERR_ARG, "n_out=%d outside [0, %d]", n_out, n);
-    if (B == 0) return 0;
+    if (B == 0) return 0;   // an empty batch has no pointers to check
+    if (!ws || !status || (p > 0 && !X)) return fail(PYMPC_ERR_ARG, "pympc_mpqp_solve_batch: null pointer");
     SolveParams P;
     memset(&P, 0, sizeof(P));
     P.ws = ws; P.ws_stride = 0; P.ws_status = nullptr;
@@ -206,8 +207,9 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
                          double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream)
 {
     if (int rc = check_shape(n, m, 0)) return rc;
-    if (B < 0 || !H || !f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: bad argument");
+    if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: negative batch size");
     if (B == 0) return 0;
+    if (!H || !f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: null pointer");
     if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
     const WsLayout L = ws_layout(n, m, 0);
     int32_t *ws_status = reinterpret_cast<int32_t *>(ws + L.total * (size_t)B);
@@ -245,10 +247,11 @@ int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, co
                            double *vmin, double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream)
 {
     if (int rc = check_shape(n, m, p)) return rc;
-    if (B < 0 || !Huu || !fu || !Au || !b || !g || !ws || !status || (p > 0 && (!Hux || !Hxx || !fx || !Ax || !X)))
-        return fail(PYMPC_ERR_ARG, "pympc_mpqp_multi_solve: null pointer");
+    if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_mpqp_multi_solve: negative batch size");
     if (x_stride != 0 && x_stride < p) return fail(PYMPC_ERR_ARG, "x_stride %lld < p", (long long)x_stride);
     if (B == 0) return 0;
+    if (!Huu || !fu || !Au || !b || !g || !ws || !status || (p > 0 && (!Hux || !Hxx || !fx || !Ax || !X)))
+        return fail(PYMPC_ERR_ARG, "pympc_mpqp_multi_solve: null pointer");
     if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
     const WsLayout L = ws_layout(n, m, p);
     int32_t *ws_status = reinterpret_cast<int32_t *>(ws + L.total * (size_t)B);
@@ -346,10 +349,10 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
     if (n < 1 || m < 1 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_lp_solve_batch: bad shape n=%d m=%d", n, m);
     if (n > kLpNMax) return fail(PYMPC_ERR_UNSUPPORTED, "n=%d exceeds the LP kernel's limit of %d variables", n, kLpNMax);
     if (m > kLpMMax) return fail(PYMPC_ERR_UNSUPPORTED, "m=%d exceeds the LP kernel's limit of %d rows", m, kLpMMax);
-    if (!f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_lp_solve_batch: null pointer");
     if (a_stride != 0 && a_stride < (int64_t)m * n) return fail(PYMPC_ERR_ARG, "a_stride %lld < m*n", (long long)a_stride);
     if (b_stride != 0 && b_stride < m) return fail(PYMPC_ERR_ARG, "b_stride %lld < m", (long long)b_stride);
     if (B == 0) return 0;
+    if (!f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_lp_solve_batch: null pointer");
     if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
     hipStream_t st = (hipStream_t)stream;
     const long long nA = a_stride == 0 ? 1 : B;

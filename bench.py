@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1000000, help="states per GPU per step")
     ap.add_argument("--scale", type=float, default=0.3, help="states ~ U(-s x_max, s x_max); 0.3 headline, 1.0 stress")
+    ap.add_argument("--cuts", choices=("cold", "warm", "off"), default="cold",
+                    help="learned infeasibility certificates: cold = table emptied before EVERY step (each step learns from "
+                         "scratch, nothing carried over), warm = kept across steps, off = plain solve")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -122,8 +125,15 @@ def main():
         g_u = torch.empty((world * B, nu), dtype=torch.float64, device=dev)
         g_s = torch.empty(world * B, dtype=torch.int32, device=dev)
 
+    use_cuts = args.cuts != "off"
+
+    def solve():
+        if args.cuts == "cold":
+            prep.reset_cuts()
+        prep.solve_batch(X, n_out=nu, out=out, use_cuts=use_cuts)
+
     def step():
-        prep.solve_batch(X, n_out=nu, out=out)
+        solve()
         if gather:
             dist.all_gather_into_tensor(g_u, out["argmin"])
             dist.all_gather_into_tensor(g_s, out["status"])
@@ -140,7 +150,7 @@ def main():
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()                      # HIP events on the stream the kernel is launched on (torch's current stream)
-        prep.solve_batch(X, n_out=nu, out=out)
+        solve()
         b.record()
         if gather:
             dist.all_gather_into_tensor(g_u, out["argmin"])
@@ -154,10 +164,25 @@ def main():
         elapsed = float(t.item())
 
     # roofline accounting: one extra untimed pass that also writes the iteration counters (deterministic kernel)
-    res = prep.solve_batch(X, n_out=nu, want_mult=False, want_active=False, want_iters=True)
+    if args.cuts == "cold":
+        prep.reset_cuts()
+    res = prep.solve_batch(X, n_out=nu, want_mult=False, want_active=False, want_iters=True, use_cuts=use_cuts)
     torch.cuda.synchronize()
     iters = res.numpy("iters")
     status = res.numpy("status")
+    cut_hits = float(((status == 1) & (iters[:, 0] == 0)).mean())
+    n_cuts = prep.n_cuts()
+    # the same launch without certificates, for reference (untimed by the metric)
+    plain_ms = None
+    if use_cuts and rank == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        prep.solve_batch(X, n_out=nu, out=out, use_cuts=False)
+        e0.record()
+        for _ in range(3):
+            prep.solve_batch(X, n_out=nu, out=out, use_cuts=False)
+        e1.record()
+        torch.cuda.synchronize()
+        plain_ms = e0.elapsed_time(e1) / 3
     F = algorithmic_flops(n, m, p, iters[:, 0], iters[:, 1])
     Fx = executed_flops(n, m, p, iters[:, 0], iters[:, 1])
     alg_bytes = B * (8 * p + 8 * nu + 8 + 4 + 4 * ((m + 31) // 32))
@@ -184,7 +209,10 @@ def main():
                        "states_per_gpu": B, "scale": args.scale, "outputs": "u0, V, status, active-set bits",
                        "exchange": "RCCL all-gather of (u0, status)" if gather else "none",
                        "feasible_fraction": float((status == 0).mean()),
-                       "mean_outer_iterations": float(iters[:, 0].mean()), "max_outer_iterations": int(iters[:, 0].max())},
+                       "mean_outer_iterations": float(iters[:, 0].mean()), "max_outer_iterations": int(iters[:, 0].max()),
+                       "infeasibility_cuts": args.cuts, "cuts_learned_per_step": n_cuts,
+                       "states_rejected_by_a_cut": cut_hits,
+                       "plain_kernel_ms_without_cuts": plain_ms},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "qp_solve_kernel<%d,true>" % (2 * ((m + 127) // 128)), "kernel_ms": kern_ms,

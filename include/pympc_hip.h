@@ -79,6 +79,24 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
                            double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
                            int32_t *iters, void *stream);
 
+/*
+ * The same solve with a table of learned infeasibility certificates (no counterpart in the reference, which
+ * solves every state from scratch at pnnls.py:216-227).  When the NNLS of a state ends with a zero residual
+ * (pnnls.py:230, "infeasible") its solution y >= 0 is a Farkas certificate M'y = 0, m(x)'y < 0 whose first part
+ * does not depend on x: it proves infeasibility of every state x' in the half-space y'm0 + (Gm y)'x' < 0.  The
+ * kernel stores up to 256 verified certificates in `cuts` and rejects later states that violate one of them by a
+ * relative margin of 1e-6 without iterating (status PYMPC_INFEASIBLE, iters (0, 0)); states nearer to the boundary
+ * take the full solve, so the feasibility decision is the reference's.  `cuts`: pympc_mpqp_cuts_doubles(p) doubles
+ * of device memory owned by the caller, zeroed by pympc_mpqp_cuts_reset before first use and whenever `ws` is
+ * prepared again; it belongs to ONE prepared mpQP, is read and appended to by the kernel (launches on different
+ * streams may share it) and can be kept across calls.  NULL, p = 0 or p > 8: no certificates (plain solve).
+ */
+size_t pympc_mpqp_cuts_doubles(int p);
+int pympc_mpqp_cuts_reset(int p, double *cuts, void *stream);
+int pympc_mpqp_solve_batch_cuts(int n, int m, int p, const double *ws, double *cuts, const double *X, int64_t B, double tol,
+                                int n_out, double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
+                                int32_t *iters, void *stream);
+
 /* -------------------------------------------------------------------------------------------------
  * Per-problem batched QP: B independent problems  min .5 x'H_k x + f_k'x  s.t. A_k x <= b_k  of equal
  * shape (n, m); equalities are folded by the caller as rows (C, -C) exactly as pnnls.py:202-207 does.

@@ -14,9 +14,13 @@
 // Optional pruning that keeps the first-hit semantics exactly: `box` holds, per region, an axis-aligned box that
 // contains every point the row test can accept (the host computes it with 2 p LPs over {A x <= b + tol}, inflated);
 // a region whose box contains none of the wave's still-searching points is skipped without touching its rows.
+// The boxes are tested 64 at a time (lane <-> region) against the axis-aligned hull of the wave's 64 points, so a wave
+// of neighbouring grid points visits the handful of regions around it instead of walking the whole list.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "invqr_wave.hpp"
 
 namespace pympc {
 
@@ -65,25 +69,50 @@ __global__ void point_location_kernel(PlParams P)
 #pragma unroll
         for (int q = 0; q < PD; ++q) x[q] = valid ? P.X[pt * PD + q] : 0.0;
         int found = -1;
-        for (int r = 0; r < P.nreg; ++r) {
-            const bool searching = valid && found < 0;
-            if (__ballot(searching) == 0ull) break;
-            bool inside = searching;
+        // axis-aligned hull of the wave's points: a region whose box misses it holds none of them
+        double wlo[PD], whi[PD];
+        if (box) {
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                wlo[q] = wmin(valid ? x[q] : 1.0e300);
+                whi[q] = wmax(valid ? x[q] : -1.0e300);
+            }
+        }
+        for (int r0 = 0; r0 < P.nreg; r0 += 64) {
+            if (__ballot(valid && found < 0) == 0ull) break;
+            // candidate regions of this block of 64, lane <-> region
+            unsigned long long cand = ~0ull;
             if (box) {
-                const double *lo = box + (size_t)r * 2 * PD, *hi = lo + PD;
+                const int rl = r0 + (tid & 63);
+                bool hit = rl < P.nreg;
+                const double *lo = box + (size_t)(hit ? rl : 0) * 2 * PD, *hi = lo + PD;
 #pragma unroll
-                for (int q = 0; q < PD; ++q) inside = inside && (x[q] >= lo[q]) && (x[q] <= hi[q]);
-                if (__ballot(inside) == 0ull) continue;
+                for (int q = 0; q < PD; ++q) hit = hit && (lo[q] <= whi[q]) && (hi[q] >= wlo[q]);
+                cand = __ballot(hit);
+            } else if (P.nreg - r0 < 64) {
+                cand = (1ull << (P.nreg - r0)) - 1ull;
             }
-            const int i1 = P.row_ptr[r + 1];
-            for (int i = P.row_ptr[r]; i < i1; ++i) {
-                double s = -bt[i];
+            while (cand != 0ull) {
+                const int r = r0 + __ffsll((long long)cand) - 1;   // list order: the first containing region wins
+                cand &= cand - 1ull;
+                bool inside = valid && found < 0;
+                if (__ballot(inside) == 0ull) break;
+                if (box) {
+                    const double *lo = box + (size_t)r * 2 * PD, *hi = lo + PD;
 #pragma unroll
-                for (int q = 0; q < PD; ++q) s = fma(At[i * PD + q], x[q], s);
-                inside = inside && (s <= P.tol);
-                if ((i & 3) == 3 && __ballot(inside) == 0ull) break;
+                    for (int q = 0; q < PD; ++q) inside = inside && (x[q] >= lo[q]) && (x[q] <= hi[q]);
+                    if (__ballot(inside) == 0ull) continue;
+                }
+                const int i1 = P.row_ptr[r + 1];
+                for (int i = P.row_ptr[r]; i < i1; ++i) {
+                    double s = -bt[i];
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) s = fma(At[i * PD + q], x[q], s);
+                    inside = inside && (s <= P.tol);
+                    if ((i & 3) == 3 && __ballot(inside) == 0ull) break;
+                }
+                if (inside) found = r;
             }
-            if (inside) found = r;
         }
         if (valid) {
             P.idx[pt] = found;

@@ -110,6 +110,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     // a matrix too large to be staged beside four problems stays in global memory (one workspace, ws_stride 0, read
     // through L2 by every wave) instead of being refused
     if (shared && shared_lds(n, P.L).total * 8 + 16 + 4 * wave_bytes > kLdsBytes) shared = false;
+    if (!shared || p < 1 || p > kCutPMax) P.cuts = nullptr;   // certificates belong to ONE mpQP with a parameter
     const size_t shared_bytes = shared ? shared_lds(n, P.L).total * 8 : 0;
     if (shared_bytes + 16 + wave_bytes > kLdsBytes)
         return fail(PYMPC_ERR_UNSUPPORTED, "QP %dx%d (p=%d) does not fit the 160 KiB LDS (%zu + %zu B)", n, m, p,
@@ -141,7 +142,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
 
 extern "C" {
 
-int pympc_hip_abi_version(void) { return 3; }
+int pympc_hip_abi_version(void) { return 4; }
 
 const char *pympc_hip_last_error(void) { return g_err; }
 
@@ -177,9 +178,24 @@ int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux
     return check_launch("qp_prepare_kernel");
 }
 
-int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *X, int64_t B, double tol, int n_out,
-                           double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
-                           int32_t *iters, void *stream)
+size_t pympc_mpqp_cuts_doubles(int p)
+{
+    if (p < 1 || p > kCutPMax) return 0;
+    return cut_table_doubles(p);
+}
+
+int pympc_mpqp_cuts_reset(int p, double *cuts, void *stream)
+{
+    if (p < 1 || p > kCutPMax) return fail(PYMPC_ERR_UNSUPPORTED, "infeasibility cuts need 1 <= p <= %d parameters, got %d", kCutPMax, p);
+    if (!cuts) return fail(PYMPC_ERR_ARG, "pympc_mpqp_cuts_reset: null pointer");
+    hipError_t e = hipMemsetAsync(cuts, 0, cut_table_doubles(p) * sizeof(double), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int pympc_mpqp_solve_batch_cuts(int n, int m, int p, const double *ws, double *cuts, const double *X, int64_t B, double tol,
+                                int n_out, double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
+                                int32_t *iters, void *stream)
 {
     if (int rc = check_shape(n, m, p)) return rc;
     if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_mpqp_solve_batch: negative batch size");
@@ -192,7 +208,16 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
     P.X = X; P.x_stride = p; P.B = B; P.tol = tol; P.n_out = n_out;
     P.argmin = n_out > 0 ? argmin : nullptr;
     P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
+    P.cuts = cuts;
     return solve_common(true, n, m, p, P, (hipStream_t)stream);
+}
+
+int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *X, int64_t B, double tol, int n_out,
+                           double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
+                           int32_t *iters, void *stream)
+{
+    return pympc_mpqp_solve_batch_cuts(n, m, p, ws, nullptr, X, B, tol, n_out, argmin, vmin, mult, active, status, iters,
+                                       stream);
 }
 
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)

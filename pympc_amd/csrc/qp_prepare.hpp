@@ -144,23 +144,36 @@ __global__ void qp_prepare_kernel(PrepParams P)
         for (int e = tid; e < rows * n; e += nt) ws[L.T + (size_t)row0 * n + e] = Ts[(e / n) * np + (e % n)];
     }
     __syncthreads();
-    // unconstrained minimiser and copies of the objective blocks
+    // unconstrained minimiser u_unc(x) = u0 + Ku x
     for (int i = tid; i < n; i += nt) {
         double s = 0.0;
         for (int q = 0; q < n; ++q) s = fma(Hi[i * ld + q], fu[q], s);
         ws[L.u0 + i] = -s;
-        ws[L.fu + i] = fu[i];
         for (int c = 0; c < p; ++c) {
             double t = 0.0;
             for (int q = 0; q < n; ++q) t = fma(Hi[i * ld + q], Hux[q * p + c], t);
             ws[L.Ku + i * p + c] = -t;
-            ws[L.Hux + i * p + c] = Hux[i * p + c];
         }
     }
-    for (int e = tid; e < n * n; e += nt) ws[L.Huu + e] = H[e];
-    for (int e = tid; e < p * p; e += nt) ws[L.Hxx + e] = Hxx[e];
-    for (int e = tid; e < p; e += nt) ws[L.fx + e] = fx[e];
-    if (tid == 0) ws[L.g] = P.gs ? P.gs[k * P.g_stride] : P.g_host;
+    __syncthreads();   // u0, Ku (global, written by this workgroup) are read back below
+    // optimal value of the unconstrained problem: V_unc(x) = .5 f(x)'u_unc(x) + .5 x'Hxx x + fx'x + g, f(x) = Hux x + fu
+    for (int e = tid; e < p * p; e += nt) {
+        const int r = e / p, c = e % p;
+        double s = Hxx[e];
+        for (int i = 0; i < n; ++i) s = fma(Hux[i * p + r], ws[L.Ku + i * p + c], s);
+        ws[L.Sxx + e] = s;
+    }
+    for (int r = tid; r < p; r += nt) {
+        double s = fx[r];
+        for (int i = 0; i < n; ++i) s = fma(Hux[i * p + r], ws[L.u0 + i], s);
+        ws[L.sx + r] = s;
+    }
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s = fma(fu[i], ws[L.u0 + i], s);
+        ws[L.s0] = fma(0.5, s, P.gs ? P.gs[k * P.g_stride] : P.g_host);
+    }
+    for (size_t e = L.s0 + 1 + tid; e < L.total; e += nt) ws[e] = 0.0;
 }
 
 }  // namespace pympc

@@ -48,13 +48,15 @@ struct SolveParams {
     int32_t *iters;             // [B x 2] or null
     int chunk;                  // problems per workgroup
     int wave_doubles;           // per-wave LDS doubles
+    double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
 };
 
 // per-wave LDS doubles for R rows, n variables, m columns
 __host__ __device__ inline int wave_lds_doubles(int n, int p, int RP)
 {
     const int R = n + 1;
-    return invqr_lds_doubles(R, RP) + (R + kVecPad) + n + p + 1;   // Q, Wi, cv, ab | rb | ub | x0
+    (void)n;
+    return invqr_lds_doubles(R, RP) + (R + kVecPad) + p + 8;   // Q, Wi, cv, ab | rb | x0 (+ 8 zeros)
 }
 
 // Column ownership: lane l owns the MT / 2 pairs of adjacent columns 128 h + 2 l, 128 h + 2 l + 1, so that a row of
@@ -63,6 +65,134 @@ __host__ __device__ inline int wave_lds_doubles(int n, int p, int RP)
 __device__ __forceinline__ int col_of(int lane, int s) { return 128 * (s >> 1) + 2 * lane + (s & 1); }
 __device__ __forceinline__ int lane_of(int j) { return (j & 127) >> 1; }
 __device__ __forceinline__ int slot_of(int j) { return 2 * (j >> 7) + (j & 1); }
+
+// ------------------------------------------------------------------------------------------ infeasibility cuts
+// A QP of the mpQP is infeasible at x  <=>  there is y >= 0 with M'y = 0 and m(x)'y < 0 (Farkas).  That is exactly what
+// the NNLS ends with when its residual is zero (pnnls.py:230: "infeasible"): A y = e_R, i.e. M'y = 0, m(x)'y = -1.  The
+// first condition does not involve x, so the SAME y proves infeasibility of every other state x' with
+//        m(x')'y = y'm0 + (Gm y)'x' = c + d'x' < 0 :
+// a half-space of the parameter space.  The feasible set of an mpQP has few facets (the cart-pole N = 20 problem: ~50
+// cuts cover 99.6 % of the infeasible states of a uniform batch), so the kernel keeps the certificates it finds in a
+// small table in global memory (per prepared mpQP, shared by every wave through L2) and tests each new state against
+// them (lane <-> cut: p + 1 FMAs) before it starts the active-set iterations, which for an infeasible state are the
+// longest of all (the passive set has to fill all n + 1 rows).  A state is rejected only when a certificate holds
+// with a relative margin of 1e-6; anything closer to the boundary takes the full solve, so the decision is the
+// reference's (its own threshold is a residual of 1e-7).  A certificate is stored only after its x-independent part
+// has been verified to rounding level (|M'y| <= 1e-11 sum |M||y| row by row).
+// Table: int32 count, int32 lock | c[kCutMax] | d_0[kCutMax] | ... | d_{p-1}[kCutMax].  One writer at a time (try-lock,
+// never waited for); an entry is complete in L2 before `count` covers it, readers bypass the non-coherent vector L1.
+constexpr int kCutMax = 256;
+constexpr int kCutPMax = 8;
+constexpr int kCutHeader = 2;
+constexpr double kCutMargin = 1e-6;
+constexpr double kCutVerify = 1e-11;
+__host__ __device__ inline size_t cut_table_doubles(int p) { return kCutHeader + (size_t)(p + 1) * kCutMax; }
+
+__device__ __forceinline__ double coherent_load(const double *a)
+{
+    return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int cut_count(const double *cuts)
+{
+    const int c = __hip_atomic_load(reinterpret_cast<const int *>(cuts), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(min(c, kCutMax));
+}
+
+// does one of the first cnt certificates prove x0 (LDS, p entries) infeasible?  One full wavefront; wave-uniform result.
+// PP = p at compile time: all loads of a lane's certificates are in flight together.
+template <int PP>
+__device__ __forceinline__ bool cut_fires_p(const double *cuts, int cnt, const double *x0)
+{
+    const int lane = threadIdx.x & 63;
+    double xq[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) xq[q] = x0[q];
+    bool fire = false;
+#pragma unroll
+    for (int h = 0; h < kCutMax / 64; ++h) {
+        if (64 * h < cnt) {   // wave-uniform
+            const int idx = lane + 64 * h;
+            const bool on = idx < cnt;
+            const double *e = cuts + kCutHeader + (on ? idx : 0);
+            double d[PP];
+            const double c = coherent_load(e);
+#pragma unroll
+            for (int q = 0; q < PP; ++q) d[q] = coherent_load(e + (size_t)(q + 1) * kCutMax);
+            double v = c, a = fabs(c);
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const double t = d[q] * xq[q];
+                v += t;
+                a += fabs(t);
+            }
+            fire = fire || (on && v < -kCutMargin * a);
+        }
+    }
+    return __ballot(fire) != 0ull;
+}
+__device__ __forceinline__ bool cut_fires(const double *cuts, int cnt, int p, const double *x0)
+{
+    switch (p) {
+    case 1: return cut_fires_p<1>(cuts, cnt, x0);
+    case 2: return cut_fires_p<2>(cuts, cnt, x0);
+    case 3: return cut_fires_p<3>(cuts, cnt, x0);
+    case 4: return cut_fires_p<4>(cuts, cnt, x0);
+    case 5: return cut_fires_p<5>(cuts, cnt, x0);
+    case 6: return cut_fires_p<6>(cuts, cnt, x0);
+    case 7: return cut_fires_p<7>(cuts, cnt, x0);
+    case 8: return cut_fires_p<8>(cuts, cnt, x0);
+    }
+    return false;
+}
+
+// The NNLS of state x0 ended with a zero residual on the passive set (lane l < k: column Pl, coefficient yl > 0,
+// m(x) entry mPl).  Verify the certificate and append it to the table unless an entry already covers x0.
+__device__ __forceinline__ void cut_learn(double *cuts, int n, int p, int mp, const double *__restrict__ Mt, int mtp,
+                                          const double *__restrict__ m0, const double *__restrict__ Gm, int k, int Pl,
+                                          double yl, double mPl, const double *x0)
+{
+    const int lane = threadIdx.x & 63;
+    if (cut_count(cuts) >= kCutMax) return;
+    // ---- x-independent part: M_P'y = 0 row by row, and the last row m_P'y = -1
+    double eps = (lane == n) ? 1.0 : 0.0, S = eps;
+    for (int l = 0; l < k; ++l) {
+        const int pj = lane_i32(Pl, l);
+        const double yy = lane_f64(yl, l), mm = lane_f64(mPl, l);
+        double a = 0.0;
+        if (lane < n) a = Mt[lane * mtp + pj];
+        else if (lane == n) a = mm;
+        eps = fma(a, yy, eps);
+        S = fma(fabs(a), fabs(yy), S);
+    }
+    const bool bad = (lane <= n && !(fabs(eps) <= kCutVerify * S)) || (lane < k && !(yl > 0.0));
+    if (__ballot(bad) != 0ull) return;
+    // ---- c = y'm0, d = Gm y: lane 0 keeps c, lane q + 1 keeps d_q
+    const int col = (lane < k) ? Pl : 0;
+    double mine = wsum(lane < k ? yl * m0[col] : 0.0);
+    double scale = fabs(mine);
+    for (int q = 0; q < p; ++q) {
+        const double dq = wsum(lane < k ? yl * Gm[(size_t)q * mp + col] : 0.0);
+        if (lane == q + 1) mine = dq;
+        scale = fmax(scale, fabs(dq));
+    }
+    if (!(scale > 0.0) || !(scale < 1e300)) return;
+    mine = mine / scale;
+    // ---- single writer
+    int *hdr = reinterpret_cast<int *>(cuts);
+    int got = 0;
+    if (lane == 0) got = (atomicCAS(hdr + 1, 0, 1) == 0) ? 1 : 0;
+    got = __builtin_amdgcn_readfirstlane(got);
+    if (!got) return;
+    const int cnt = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hdr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+    if (cnt >= 0 && cnt < kCutMax && !cut_fires(cuts, cnt, p, x0)) {
+        if (lane <= p)
+            __hip_atomic_store(cuts + kCutHeader + (size_t)lane * kCutMax + cnt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(hdr, cnt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(hdr + 1, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Solve problem `prob`.  Mt (row pitch mtp) / m0 / Gm point to LDS (shared-matrix launch) or to this problem's global
 // workspace; tab[L.u0 ...] are the small objective tables (LDS copy or the global workspace), wsg the global workspace
@@ -85,18 +215,23 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     InvQr F;
     invqr_bind(F, wl, R, RP);
     double *rb = wl + invqr_lds_doubles(R, RP);
-    double *ub = rb + R + kVecPad;
-    double *x0 = ub + n;   // the parameter vector, staged once (every later use is an LDS broadcast, not an HBM round trip)
+    double *x0 = rb + R + kVecPad;   // the parameter vector, staged once and followed by 8 zeros (LDS broadcasts later on)
     if (lane < p) x0[lane] = P.X[prob * P.x_stride + lane];
     if (lane < R) F.cv[lane] = (lane == n) ? 1.0 : 0.0;   // cv = Qt e_R with Qt = I
+    const int ncut = P.cuts ? cut_count(P.cuts) : 0;
     wave_sync_lds();
 
 #ifdef PYMPC_PHASE_TIMING
     long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();   // debug build: cycles per phase, written over mult[0..7]
 #endif
+    // ---- a stored certificate proves this state infeasible: no iterations
+    const bool cut_hit = ncut > 0 && cut_fires(P.cuts, ncut, p, x0);
+
     // ---- m(x) = m0 + Gm' x : the per-problem row of the NNLS matrix (pnnls.py:214)
     double mv[MT], w[MT];
-    {
+#pragma unroll
+    for (int s = 0; s < MT; ++s) mv[s] = 0.0;
+    if (!cut_hit) {
         const double2 *m2 = reinterpret_cast<const double2 *>(m0) + lane;
 #pragma unroll
         for (int h = 0; h < MT / 2; ++h) {
@@ -104,20 +239,31 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
             mv[2 * h] = v.x;
             mv[2 * h + 1] = v.y;
         }
-        for (int q = 0; q < p; ++q) {
-            const double xq = x0[q];
-            const double2 *g2 = reinterpret_cast<const double2 *>(Gm + q * mp) + lane;
+        constexpr int QU = MT <= 8 ? 4 : (MT <= 16 ? 2 : 1);   // rows of Gm whose loads are in flight together
+        for (int q0 = 0; q0 < p; q0 += QU) {
+            double2 gv[QU][MT / 2];
+            double xv[QU];
 #pragma unroll
-            for (int h = 0; h < MT / 2; ++h) {
-                const double2 v = g2[64 * h];
-                mv[2 * h] = fma(v.x, xq, mv[2 * h]);
-                mv[2 * h + 1] = fma(v.y, xq, mv[2 * h + 1]);
+            for (int u = 0; u < QU; ++u) {
+                const int q = min(q0 + u, p - 1);
+                const double xq = x0[q];
+                xv[u] = (q0 + u < p) ? xq : 0.0;
+                const double2 *g2 = reinterpret_cast<const double2 *>(Gm + q * mp) + lane;
+#pragma unroll
+                for (int h = 0; h < MT / 2; ++h) gv[u][h] = g2[64 * h];
             }
+#pragma unroll
+            for (int u = 0; u < QU; ++u)
+#pragma unroll
+                for (int h = 0; h < MT / 2; ++h) {
+                    mv[2 * h] = fma(gv[u][h].x, xv[u], mv[2 * h]);
+                    mv[2 * h + 1] = fma(gv[u][h].y, xv[u], mv[2 * h + 1]);
+                }
         }
     }
 
     uint32_t inP = 0;   // bit s: column lane + 64 s is in the passive set
-    int k = 0, iter = 0, outer = 0, status = prepared_ok ? kStatusOptimal : kStatusNotPD;
+    int k = 0, iter = 0, outer = 0, status = prepared_ok ? (cut_hit ? kStatusInfeasible : kStatusOptimal) : kStatusNotPD;
     int Pl = -1;        // lane l < k: column index at position l of the passive set
     double yl = 0.0;    // ... its coefficient
     double mPl = 0.0;   // ... its m(x) entry
@@ -253,28 +399,34 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 
     PYMPC_TICK(6)
     // ---------------- residual norm and outputs (pnnls.py:230-239, parametric_programs.py:176-177)
-    const double cl = (lane >= k && lane < R) ? F.cv[lane] : 0.0;
-    const double rnorm = sqrt(wsum(cl * cl));
-    if (status == kStatusOptimal && !(rnorm > P.tol)) status = kStatusInfeasible;
+    // Three sums in one butterfly: the squared NNLS residual |cv[k:]|^2, m'y, and the unconstrained value V_unc(x).
+    const WsLayout &L = P.L;
+    double r2 = 0.0, my = 0.0, vq = 0.0;
+    if (qt_ready && lane >= k && lane < R) {
+        const double cl = F.cv[lane];
+        r2 = cl * cl;
+    }
+    if (lane < k) my = mPl * yl;
+    if (P.vmin && lane < p) vq = x0[lane] * fma(0.5, dotu(tab + L.Sxx + lane * p, x0, p), tab[L.sx + lane]);
+    wsum3(r2, my, vq);
+    const double rnorm = qt_ready ? fast_sqrt(r2) : 1.0;   // Qt = I, cv = e_R before the first column enters
+    if (status == kStatusOptimal && !(rnorm > P.tol)) {
+        status = kStatusInfeasible;
+        if (P.cuts && k > 0) cut_learn(P.cuts, n, p, mp, Mt, mtp, m0, Gm, k, Pl, yl, mPl, x0);
+    }
     const bool okk = (status == kStatusOptimal);
     const int nw = (m + 31) / 32;
     const double nanv = __builtin_nan("");
 
-    double lam = 0.0;
-    if (okk) {
-        const double my = wsum(lane < k ? mPl * yl : 0.0);
-        lam = (lane < k) ? yl / (1.0 + my) : 0.0;
-    }
-    if (P.argmin || P.vmin) {
-        double ui = nanv, V = nanv;
+    // lambda = y / (1 + m'y) (pnnls.py:231).  With gamma = 1 + m'y the optimal value needs nothing else: the NNLS
+    // optimality conditions give |M'y|^2 = -m'y gamma, hence V - V_unc = .5 |L^-1 A_P'lambda|^2 = -.5 m'y / gamma.
+    const double ginv = okk ? fast_div(1.0, 1.0 + my) : 0.0;
+    const double lam = (lane < k) ? yl * ginv : 0.0;
+    if (P.argmin) {
+        double ui = nanv;
         if (okk) {
-            const WsLayout &L = P.L;
             ui = 0.0;
-            double fi = 0.0;
-            if (lane < n) {
-                ui = dot8(tab + L.Ku + lane * p, 1, x0, 1, 0, p, tab[L.u0 + lane]);
-                fi = dot8(tab + L.Hux + lane * p, 1, x0, 1, 0, p, tab[L.fu + lane]);
-            }
+            if (lane < P.n_out) ui = dotu(tab + L.Ku + lane * p, x0, p, tab[L.u0 + lane]);
             for (int l0 = 0; l0 < k; l0 += 8) {   // u -= sum_l lam_l (Huu^-1 a_Pl): rows of T, eight gathers in flight
                 double tv[8], ll[8];
 #pragma unroll
@@ -282,30 +434,17 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
                     const int l = min(l0 + u, k - 1);
                     ll[u] = lane_f64(lam, l);
                     const int pj = lane_i32(Pl, l);
-                    tv[u] = (lane < n) ? wsg[L.T + (size_t)pj * n + lane] : 0.0;
+                    tv[u] = (lane < P.n_out) ? wsg[L.T + (size_t)pj * n + lane] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (l0 + u < k) ui = fma(-ll[u], tv[u], ui);
             }
-            if (P.vmin) {
-                if (lane < n) ub[lane] = ui;
-                wave_sync_lds();
-                double term = 0.0;
-                if (lane < n) {   // (u'Huu)[lane] as pnnls.py:234 evaluates x.dot(H): column `lane` of Huu
-                    const double hi = dot8(ub, 1, tab + L.Huu + lane, n, 0, n);
-                    term = ui * (0.5 * hi + fi);
-                }
-                if (lane < p) {
-                    const double hx = dot8(x0, 1, tab + L.Hxx + lane, p, 0, p);
-                    term += x0[lane] * (0.5 * hx + tab[L.fx + lane]);
-                }
-                V = wsum(term) + tab[L.g];
-            }
         }
-        if (P.argmin && lane < P.n_out) P.argmin[prob * P.n_out + lane] = ui;
-        if (P.vmin && lane == 0) P.vmin[prob] = V;
+        if (lane < P.n_out) P.argmin[prob * P.n_out + lane] = ui;
     }
+    if (P.vmin && lane == 0) P.vmin[prob] = okk ? (tab[L.s0] + vq) - 0.5 * my * ginv : nanv;
+#ifndef PYMPC_PHASE_TIMING   // (the debug build reports its cycle counts through mult)
     if (P.mult) {
 #pragma unroll
         for (int s = 0; s < MT; ++s) {
@@ -314,6 +453,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
         }
         if (okk && lane < k) P.mult[prob * m + Pl] = lam;
     }
+#endif
     if (P.active) {   // word `lane` of the bit mask: OR over the passive positions that fall into it (m <= 2048: <= 64 words)
         const unsigned long long act = __ballot(okk && lane < k && lam > P.tol);
         uint32_t word = 0u;
@@ -347,7 +487,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 
 // LDS image of the constant part for the shared-matrix launch: Mt rows pitched by mp + 2 doubles (the column gather
 // Mt[lane][j] of the candidate test then spreads over 16 bank groups instead of one), and the small objective tables
-// ws[L.u0 .. L.total) (u0, Ku, Huu, Hux, fu, Hxx, fx, g).  m0 and Gm are read once per problem (m(x) = m0 + Gm'x), from
+// ws[L.u0 .. L.total) (u0, Ku, Sxx, sx, s0, zeros).  m0 and Gm are read once per problem (m(x) = m0 + Gm'x), from
 // L2: keeping them out of LDS buys two more problems in flight per CU.
 struct SharedLds {
     int mtp;

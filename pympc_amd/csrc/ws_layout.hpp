@@ -8,7 +8,11 @@
 //   Gm  [p  x mp]
 //   T   [m  x n]    T = Au Huu^-1   (row j = (Huu^-1 a_j)')      (primal recovery, pnnls.py:233)
 //   u0  [n], Ku [n x p]   unconstrained minimiser u_unc(x) = u0 + Ku x = -Huu^-1 f(x)
-//   Huu [n x n], Hux [n x p], fu [n], Hxx [p x p], fx [p], g [1]   (objective, pnnls.py:234 + parametric_programs.py:177)
+//   Sxx [p x p], sx [p], s0 [1]   optimal value of the UNCONSTRAINED problem, V_unc(x) = .5 x'Sxx x + sx'x + s0 with
+//                         Sxx = Hxx + Hux'Ku, sx = fx + Hux'u0, s0 = g + .5 fu'u0.  The kernel lifts it to the value
+//                         of pnnls.py:234 + parametric_programs.py:177 with the NNLS solution alone:
+//                         V = V_unc(x) + .5 |M'lambda|^2 = V_unc(x) - .5 m'y / (1 + m'y)   (see qp_wave.hpp)
+//   zeros up to `total` (the short dots of the kernels read up to 7 doubles past a row: they must be finite)
 //
 // Columns are padded to mp = 64 * MT (MT = columns per lane, even) so that every lane of a wavefront owns MT
 // columns (MT / 2 pairs of adjacent columns: lane l owns 128 h + 2 l and 128 h + 2 l + 1, h = 0 .. MT/2 - 1); pad columns have Mt = 0, Gm = 0, m0 = 1 (their dual w = -1 is never selected).
@@ -39,7 +43,7 @@ __host__ __device__ inline int mt_bucket(int m)
 
 struct WsLayout {
     int mp;
-    size_t Mt, m0, Gm, T, u0, Ku, Huu, Hux, fu, Hxx, fx, g, total;
+    size_t Mt, m0, Gm, T, u0, Ku, Sxx, sx, s0, total;
 };
 
 __host__ __device__ inline WsLayout ws_layout(int n, int m, int p)
@@ -53,13 +57,10 @@ __host__ __device__ inline WsLayout ws_layout(int n, int m, int p)
     L.T = L.Gm + (size_t)p * mp;
     L.u0 = L.T + (size_t)m * n;
     L.Ku = L.u0 + n;
-    L.Huu = L.Ku + (size_t)n * p;
-    L.Hux = L.Huu + (size_t)n * n;
-    L.fu = L.Hux + (size_t)n * p;
-    L.Hxx = L.fu + n;
-    L.fx = L.Hxx + (size_t)p * p;
-    L.g = L.fx + p;
-    L.total = (L.g + 1 + 31) / 32 * 32;   // keep per-problem workspaces 256-byte aligned
+    L.Sxx = L.Ku + (size_t)n * p;
+    L.sx = L.Sxx + (size_t)p * p;
+    L.s0 = L.sx + p;
+    L.total = (L.s0 + 1 + 8 + 31) / 32 * 32;   // >= 8 zeros after s0; per-problem workspaces stay 256-byte aligned
     return L;
 }
 

@@ -128,10 +128,24 @@ class PreparedMpqp(object):
                                           _hip.ptr(b_), _hip.ptr(self.ws), _hip.ptr(self.ws_status), _hip.stream_ptr()))
         if int(self.ws_status.item()) == _hip.NOT_PD:
             raise np.linalg.LinAlgError('Matrix is not positive definite')
+        # learned infeasibility certificates of this mpQP (include/pympc_hip.h: pympc_mpqp_solve_batch_cuts)
+        nc = lib.pympc_mpqp_cuts_doubles(self.p)
+        self.cuts = torch.zeros(nc, dtype=torch.float64, device=self.dev) if nc > 0 else None
+
+    def reset_cuts(self):
+        """Forget the infeasibility certificates learned so far (asynchronous on the current stream)."""
+        if self.cuts is not None:
+            _hip.check(_hip.load_library().pympc_mpqp_cuts_reset(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
+
+    def n_cuts(self):
+        return 0 if self.cuts is None else int(self.cuts[:1].view(torch.int32)[0].item())
 
     def solve_batch(self, X, tol=TOL, n_out=None, want_mult=True, want_active=True, want_iters=False, want_min=True,
-                    out=None):
-        """X: [B x p] (numpy or device tensor).  Returns a BatchResult (device tensors, nothing synchronised)."""
+                    out=None, use_cuts=True):
+        """X: [B x p] (numpy or device tensor).  Returns a BatchResult (device tensors, nothing synchronised).
+
+        use_cuts: reject states that a stored Farkas certificate proves infeasible before iterating, and store the
+        certificates of the states found infeasible by the full solve (same statuses either way)."""
         lib = _hip.load_library()
         X = _hip.to_device(X)
         if X.dim() != 2 or X.shape[1] != self.p:
@@ -140,10 +154,11 @@ class PreparedMpqp(object):
         n_out = self.n if n_out is None else n_out
         if out is None:
             out = _alloc_outputs(B, n_out, self.m, self.dev, want_mult, want_active, want_iters, want_min)
-        _hip.check(lib.pympc_mpqp_solve_batch(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(X), B, float(tol), n_out,
-                                              _hip.ptr(out['argmin']), _hip.ptr(out['min']),
-                                              _hip.ptr(out['multiplier_inequality']), _hip.ptr(out['active_bits']),
-                                              _hip.ptr(out['status']), _hip.ptr(out['iters']), _hip.stream_ptr()))
+        cuts = self.cuts if use_cuts else None
+        _hip.check(lib.pympc_mpqp_solve_batch_cuts(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(cuts), _hip.ptr(X), B,
+                                                   float(tol), n_out, _hip.ptr(out['argmin']), _hip.ptr(out['min']),
+                                                   _hip.ptr(out['multiplier_inequality']), _hip.ptr(out['active_bits']),
+                                                   _hip.ptr(out['status']), _hip.ptr(out['iters']), _hip.stream_ptr()))
         return BatchResult(self.m, **out)
 
 

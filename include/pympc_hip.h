@@ -186,12 +186,18 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
  * box [nreg x 2 p] (p lower bounds, then p upper bounds; may be NULL): per region an axis-aligned box that contains
  * every point its row test can accept; regions whose box holds none of a wavefront's points are skipped.  It only
  * prunes: the result is the reference's first-hit region whatever the boxes are, as long as they are not too small.
+ * Cell grid (may be NULL / 0): grid_geom [2 p] = lower corner of a uniform grid of grid_n cells per axis, then
+ * 1 / cell size per axis; grid_masks [grid_n^p x ceil(nreg/64)] uint64, cell index = ((c_0 grid_n + c_1) grid_n + ...),
+ * bit r % 64 of word r / 64 set iff region r can contain a point of the cell (points outside the grid are looked up
+ * in the nearest cell).  Like the boxes it only prunes: a missing bit is only allowed for a region that contains no
+ * point of the cell.
  * Outputs: idx [B] int32 (-1 when uncovered), u [B x nu] (NaN when uncovered), V [B] (NaN when uncovered).
  * ------------------------------------------------------------------------------------------------- */
 int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
                          const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
-                         const double *Vx, const double *V0, const double *box, const double *X, int64_t B, double tol,
-                         int32_t *idx, double *u, double *V, void *stream);
+                         const double *Vx, const double *V0, const double *box, const double *grid_geom, int grid_n,
+                         const uint64_t *grid_masks, const double *X, int64_t B, double tol, int32_t *idx, double *u,
+                         double *V, void *stream);
 
 #ifdef __cplusplus
 }

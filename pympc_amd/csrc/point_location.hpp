@@ -6,8 +6,8 @@
 // u = ux x + u0 (parametric_programs.py:364) and V = .5 x'Vxx x + Vx'x + V0 (:398); uncovered points give None.
 //
 // MI355X mapping: the streaming side is HBM-bound (p doubles in, 4 + 8 nu + 8 bytes out per point, coalesced),
-// the table side is kept out of HBM: all region rows (A | b) are staged once per workgroup in LDS and every lane
-// of a wavefront scans the SAME region row at the same time, so each ds_read is a broadcast (no bank conflicts).
+// the table side is kept out of HBM and out of the vector memory path: every lane of a wavefront scans the SAME
+// region row at the same time, so the rows (A | b) are fetched with scalar loads through the scalar data cache / L2.
 // A region is abandoned as soon as every still-searching lane of the wave has violated one of its rows, and the
 // scan stops when every lane has found its region; neighbouring grid points mostly share regions, so the wave
 // rarely does more rows than its slowest lane needs.
@@ -16,6 +16,10 @@
 // a region whose box contains none of the wave's still-searching points is skipped without touching its rows.
 // The boxes are tested 64 at a time (lane <-> region) against the axis-aligned hull of the wave's 64 points, so a wave
 // of neighbouring grid points visits the handful of regions around it instead of walking the whole list.
+// Critical regions are often thin slabs whose boxes overlap most of the domain, so the host may add a uniform cell
+// grid over the parameter space with, per cell, the bit set of regions that no row separates from the cell
+// (grid_masks); the wave ORs the bit sets of the few cells its hull touches (lane <-> cell).  Same contract as the
+// boxes: bits may only be missing for regions that contain no point of the cell.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,11 +29,14 @@
 namespace pympc {
 
 struct PlParams {
-    int nreg, p, nu, total_rows, table_in_lds, box_in_lds;
+    int nreg, p, nu, total_rows;
     const double *A, *b;
     const int32_t *row_ptr;
     const double *ux, *u0, *Vxx, *Vx, *V0;
     const double *box;   // [nreg x 2 p] (lower bounds, then upper bounds) or null
+    const double *grid_geom;              // [2 p]: lower corner of the cell grid, then 1 / cell size per axis; or null
+    const unsigned long long *grid_masks; // [grid_n^p x ceil(nreg / 64)]: bit r of a cell = region r can touch the cell
+    int grid_n;                           // cells per axis
     const double *X;
     long long B;
     double tol;
@@ -37,27 +44,36 @@ struct PlParams {
     double *u, *V;
 };
 
+constexpr int kPlRows = 8;   // region rows tested per batch
+
+using cdouble_ptr = const double __attribute__((address_space(4))) *;
+using cint_ptr = const int __attribute__((address_space(4))) *;
+__device__ __forceinline__ cdouble_ptr as_const(const double *p) { return (cdouble_ptr)p; }
+
+// bitwise OR of a 64-bit value over the wavefront (every lane gets the result)
+__device__ __forceinline__ unsigned long long wor64(unsigned long long v)
+{
+    int lo = (int)(v & 0xffffffffull), hi = (int)(v >> 32);
+#define PYMPC_WOR_STEP(CTRL) { lo |= dpp_i32<CTRL>(lo); hi |= dpp_i32<CTRL>(hi); }
+    PYMPC_WOR_STEP(kDppXor1)
+    PYMPC_WOR_STEP(kDppXor2)
+    PYMPC_WOR_STEP(kDppHalfMirror)
+    PYMPC_WOR_STEP(kDppMirror)
+#undef PYMPC_WOR_STEP
+    lo = (lane_i32(lo, 0) | lane_i32(lo, 16)) | (lane_i32(lo, 32) | lane_i32(lo, 48));
+    hi = (lane_i32(hi, 0) | lane_i32(hi, 16)) | (lane_i32(hi, 32) | lane_i32(hi, 48));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+
 template <int PD>
 __global__ void point_location_kernel(PlParams P)
 {
-    extern __shared__ double lds[];
     const int tid = threadIdx.x;
-    const double *At = P.A, *bt = P.b;
-    if (P.table_in_lds) {
-        const int na = P.total_rows * PD;
-        for (int e = tid; e < na; e += blockDim.x) lds[e] = P.A[e];
-        for (int e = tid; e < P.total_rows; e += blockDim.x) lds[na + e] = P.b[e];
-        __syncthreads();
-        At = lds;
-        bt = lds + na;
-    }
-    const double *box = P.box;
-    if (P.box && P.box_in_lds) {
-        double *bl = lds + (P.table_in_lds ? P.total_rows * (PD + 1) : 0);
-        for (int e = tid; e < P.nreg * 2 * PD; e += blockDim.x) bl[e] = P.box[e];
-        __syncthreads();
-        box = bl;
-    }
+    // The table is read-only for the kernel's lifetime and every row access is wave-uniform: through the constant
+    // address space those become scalar loads (one s_load per batch of rows into SGPRs, the FMAs take them as scalar
+    // operands) instead of 64-lane vector loads of one address, which were what bounded this kernel.
+    const cdouble_ptr At = as_const(P.A), bt = as_const(P.b), box = as_const(P.box);
+    const cint_ptr row_ptr = reinterpret_cast<cint_ptr>(as_const(reinterpret_cast<const double *>(P.row_ptr)));
     const double nanv = __builtin_nan("");
     const long long stride = (long long)gridDim.x * blockDim.x;
     // every lane of a wave runs the same number of grid-stride rounds (wave-uniform loop bound)
@@ -71,45 +87,90 @@ __global__ void point_location_kernel(PlParams P)
         int found = -1;
         // axis-aligned hull of the wave's points: a region whose box misses it holds none of them
         double wlo[PD], whi[PD];
-        if (box) {
+        if (box || P.grid_masks) {
 #pragma unroll
             for (int q = 0; q < PD; ++q) {
                 wlo[q] = wmin(valid ? x[q] : 1.0e300);
                 whi[q] = wmax(valid ? x[q] : -1.0e300);
             }
         }
+        // cells of the grid that the hull touches: lane l < ncell looks one of them up
+        int ncell = 0;
+        long long mycell = 0;
+        if (P.grid_masks && __ballot(valid) != 0ull) {
+            int c0[PD], cn[PD];
+            long long tot = 1;
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                const double g0 = P.grid_geom[q], gi = P.grid_geom[PD + q], gmax = (double)(P.grid_n - 1);
+                const double a = fmin(fmax(floor((wlo[q] - g0) * gi), 0.0), gmax);
+                const double b = fmin(fmax(floor((whi[q] - g0) * gi), 0.0), gmax);
+                c0[q] = (int)a;
+                cn[q] = (int)b - (int)a + 1;
+                tot *= cn[q];
+            }
+            if (tot <= 64) {
+                ncell = (int)tot;
+                int l = min(tid & 63, ncell - 1);
+#pragma unroll
+                for (int q = 0; q < PD; ++q) {
+                    mycell = mycell * P.grid_n + c0[q] + l % cn[q];
+                    l /= cn[q];
+                }
+            }
+        }
+        const int nwords = (P.nreg + 63) >> 6;
         for (int r0 = 0; r0 < P.nreg; r0 += 64) {
             if (__ballot(valid && found < 0) == 0ull) break;
             // candidate regions of this block of 64, lane <-> region
             unsigned long long cand = ~0ull;
+            if (ncell > 0) {
+                unsigned long long mk = 0ull;
+                if ((tid & 63) < ncell) mk = P.grid_masks[mycell * nwords + (r0 >> 6)];
+                cand = wor64(mk);
+                if (cand == 0ull) continue;
+            }
             if (box) {
                 const int rl = r0 + (tid & 63);
                 bool hit = rl < P.nreg;
-                const double *lo = box + (size_t)(hit ? rl : 0) * 2 * PD, *hi = lo + PD;
+                const double *lo = P.box + (size_t)(hit ? rl : 0) * 2 * PD, *hi = lo + PD;   // lane <-> region: vector loads
 #pragma unroll
                 for (int q = 0; q < PD; ++q) hit = hit && (lo[q] <= whi[q]) && (hi[q] >= wlo[q]);
-                cand = __ballot(hit);
+                cand &= __ballot(hit);
             } else if (P.nreg - r0 < 64) {
-                cand = (1ull << (P.nreg - r0)) - 1ull;
+                cand &= (1ull << (P.nreg - r0)) - 1ull;
             }
             while (cand != 0ull) {
-                const int r = r0 + __ffsll((long long)cand) - 1;   // list order: the first containing region wins
+                const int r = __builtin_amdgcn_readfirstlane(r0 + __ffsll((long long)cand) - 1);   // list order: the first containing region wins
                 cand &= cand - 1ull;
                 bool inside = valid && found < 0;
                 if (__ballot(inside) == 0ull) break;
                 if (box) {
-                    const double *lo = box + (size_t)r * 2 * PD, *hi = lo + PD;
+                    const cdouble_ptr lo = box + (size_t)r * 2 * PD, hi = lo + PD;
 #pragma unroll
                     for (int q = 0; q < PD; ++q) inside = inside && (x[q] >= lo[q]) && (x[q] <= hi[q]);
                     if (__ballot(inside) == 0ull) continue;
                 }
-                const int i1 = P.row_ptr[r + 1];
-                for (int i = P.row_ptr[r]; i < i1; ++i) {
-                    double s = -bt[i];
+                // rows in batches of kPlRows: all loads of a batch are issued before the first FMA (a row-at-a-time loop
+                // pays one memory round trip per row); the clamped repeats of the last row test the same condition again
+                const int i1 = __builtin_amdgcn_readfirstlane(row_ptr[r + 1]);
+                for (int i = __builtin_amdgcn_readfirstlane(row_ptr[r]); i < i1; i += kPlRows) {
+                    double a[kPlRows][PD], bb[kPlRows];
 #pragma unroll
-                    for (int q = 0; q < PD; ++q) s = fma(At[i * PD + q], x[q], s);
-                    inside = inside && (s <= P.tol);
-                    if ((i & 3) == 3 && __ballot(inside) == 0ull) break;
+                    for (int u = 0; u < kPlRows; ++u) {
+                        const int ii = min(i + u, i1 - 1);
+                        bb[u] = bt[ii];
+#pragma unroll
+                        for (int q = 0; q < PD; ++q) a[u][q] = At[ii * PD + q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kPlRows; ++u) {
+                        double s = -bb[u];
+#pragma unroll
+                        for (int q = 0; q < PD; ++q) s = fma(a[u][q], x[q], s);
+                        inside = inside && (s <= P.tol);
+                    }
+                    if (__ballot(inside) == 0ull) break;
                 }
                 if (inside) found = r;
             }

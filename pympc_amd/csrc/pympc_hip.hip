@@ -422,8 +422,9 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
 
 int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
                          const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
-                         const double *Vx, const double *V0, const double *box, const double *X, int64_t B, double tol,
-                         int32_t *idx, double *u, double *V, void *stream)
+                         const double *Vx, const double *V0, const double *box, const double *grid_geom, int grid_n,
+                         const uint64_t *grid_masks, const double *X, int64_t B, double tol, int32_t *idx, double *u,
+                         double *V, void *stream)
 {
     if (nreg < 0 || total_rows < 0 || p < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_point_location: bad shape");
     if (p > 8) return fail(PYMPC_ERR_UNSUPPORTED, "point location supports up to 8 parameters, got %d", p);
@@ -436,17 +437,17 @@ int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *
     P.nreg = nreg; P.p = p; P.nu = nu; P.total_rows = total_rows;
     P.A = A; P.b = b; P.row_ptr = row_ptr; P.ux = ux; P.u0 = u0; P.Vxx = Vxx; P.Vx = Vx; P.V0 = V0;
     P.box = box; P.X = X; P.B = B; P.tol = tol; P.idx = idx; P.u = u; P.V = V;
-    const size_t table_bytes = (size_t)total_rows * (p + 1) * 8;
-    // with pruning boxes a wave touches the rows of a few regions only: leave a large table in L2 / L1 and keep the
-    // LDS for occupancy (the boxes are 16 p bytes per region)
-    P.table_in_lds = table_bytes <= (box ? 16 * 1024 : 150 * 1024);
-    size_t lds = P.table_in_lds ? table_bytes : 0;
-    const size_t box_bytes = box ? (size_t)nreg * 2 * p * 8 : 0;
-    P.box_in_lds = box && lds + box_bytes <= 150 * 1024;
-    if (P.box_in_lds) lds += box_bytes;
+    if (grid_geom && grid_masks && grid_n > 0) {
+        double cells = 1.0;
+        for (int q = 0; q < p; ++q) cells *= grid_n;
+        if (cells > 1e8) return fail(PYMPC_ERR_ARG, "pympc_point_location: grid of %d^%d cells", grid_n, p);
+        P.grid_geom = grid_geom; P.grid_n = grid_n;
+        P.grid_masks = reinterpret_cast<const unsigned long long *>(grid_masks);
+    }
+    const size_t lds = 0;
     const int threads = 256;
     long long nwg = (B + threads - 1) / threads;
-    const long long cap = 256LL * (lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 8)) * 4;   // grid-stride beyond a few waves of workgroups
+    const long long cap = 256LL * 8 * 4;   // grid-stride beyond a few waves of workgroups
     if (nwg > cap) nwg = cap;
     hipStream_t st = (hipStream_t)stream;
 #define PYMPC_PL_CASE(PD)                                                                         \

@@ -285,6 +285,10 @@ class ExplicitSolution(object):
         t['box'] = self._bounding_boxes(t, tol=1.e-7)
         t['dev'] = {k: _hip.to_device(t[k]) for k in ('A', 'b', 'ux', 'u0', 'Vxx', 'Vx', 'V0', 'box')}
         t['dev']['row_ptr'] = _hip.to_device(row_ptr, dtype=torch.int32)
+        t['grid'] = self._cell_grid(t, tol=1.e-7)
+        if t['grid'] is not None:
+            t['dev']['grid_geom'] = _hip.to_device(t['grid']['geom'])
+            t['dev']['grid_masks'] = torch.as_tensor(t['grid']['masks'].view(np.int64)).to(_hip.device())
         self._table = t
         return t
 
@@ -325,7 +329,46 @@ class ExplicitSolution(object):
         box[:, p:] = hi + pad * (1. + np.abs(hi))
         return box
 
-    def locate(self, X, nu=None, tol=1.e-7, use_boxes=True):
+    GRID_CELLS_PER_AXIS = {1: 4096, 2: 128, 3: 32, 4: 12}
+
+    @classmethod
+    def _cell_grid(cls, t, tol):
+        """
+        Uniform grid over the union of the region boxes with, per cell, the bit set of regions that can contain a point
+        of the cell: region r is dropped from a cell only when one of its rows a'x <= b + tol is violated on the whole
+        (slightly inflated) cell, i.e. min over the cell of a'x = sum_q min(a_q lo_q, a_q hi_q) > b + tol.  Critical
+        regions are mostly thin slabs: their boxes overlap everywhere, this test does not.  None when the parameter
+        space has more than 4 dimensions or a region is unbounded.
+        """
+        nreg, p, rp = t['nreg'], t['p'], t['row_ptr']
+        G = cls.GRID_CELLS_PER_AXIS.get(p)
+        box = t['box']
+        if G is None or nreg == 0 or not np.all(np.isfinite(box)):
+            return None
+        lo = box[:, :p].min(axis=0)
+        hi = box[:, p:].max(axis=0)
+        span = hi - lo
+        if not np.all(span > 0):
+            return None
+        h = span / G
+        axes = [np.arange(G)] * p
+        idx = np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, p)     # cell index = ((c0 G + c1) G + ...)
+        pad = 1.e-9 * (1. + np.abs(lo) + np.abs(hi))          # rounding of the kernel's cell index, LP accuracy of the boxes
+        clo = lo + idx * h - pad
+        chi = lo + (idx + 1) * h + pad
+        # the kernel clamps points outside the grid into the border cells: those cells extend to the region boxes' hull,
+        # and no region accepts a point outside its own box, so the clamped look-up stays exact
+        masks = np.zeros((idx.shape[0], (nreg + 63) // 64), dtype=np.uint64)
+        for r in range(nreg):
+            A = t['A'][rp[r]:rp[r + 1]]
+            b = t['b'][rp[r]:rp[r + 1]] + tol + 1.e-9
+            ok = np.ones(idx.shape[0], dtype=bool)
+            for a, bi in zip(A, b):
+                ok &= (np.minimum(a * clo, a * chi).sum(axis=1) <= bi)
+            masks[ok, r // 64] |= np.uint64(1) << np.uint64(r % 64)
+        return dict(n=G, geom=np.concatenate((lo, 1. / h)), masks=masks)
+
+    def locate(self, X, nu=None, tol=1.e-7, use_boxes=True, use_grid=True):
         """Batched look-up: X [B x p] -> device tensors (idx int32 [B], u [B x nu], V [B]); no synchronisation."""
         lib = _hip.load_library()
         t = self.table(nu)
@@ -338,10 +381,13 @@ class ExplicitSolution(object):
         u = torch.empty((B, t['nu']), dtype=torch.float64, device=dev)
         V = torch.empty(B, dtype=torch.float64, device=dev)
         d = t['dev']
+        grid = use_grid and tol <= 1.e-7 and t['grid'] is not None
         _hip.check(lib.pympc_point_location(t['nreg'], t['total_rows'], t['p'], t['nu'], _hip.ptr(d['A']), _hip.ptr(d['b']),
                                             _hip.ptr(d['row_ptr']), _hip.ptr(d['ux']), _hip.ptr(d['u0']), _hip.ptr(d['Vxx']),
                                             _hip.ptr(d['Vx']), _hip.ptr(d['V0']),
-                                            _hip.ptr(d['box']) if (use_boxes and tol <= 1.e-7) else None, _hip.ptr(X), B, float(tol),
+                                            _hip.ptr(d['box']) if (use_boxes and tol <= 1.e-7) else None,
+                                            _hip.ptr(d['grid_geom']) if grid else None, t['grid']['n'] if grid else 0,
+                                            _hip.ptr(d['grid_masks']) if grid else None, _hip.ptr(X), B, float(tol),
                                             _hip.ptr(idx), _hip.ptr(u), _hip.ptr(V), _hip.stream_ptr()))
         return idx, u, V
 

@@ -143,10 +143,18 @@ def test_point_location_vs_oracle(nb, oracle):
         assert np.all(np.isnan(V[unc])) and np.all(np.isnan(u[unc]))
     assert (ridx >= 0).mean() > .3 and (ridx < 0).sum() > 1000
     # the bounding-box pruning only skips work: identical outputs with and without it, ties included
-    a = es.locate(X, nu=1, use_boxes=True); c = es.locate(X, nu=1, use_boxes=False)
+    c = es.locate(X, nu=1, use_boxes=False, use_grid=False)      # plain list scan
+    for kw in (dict(use_boxes=True, use_grid=False), dict(use_boxes=False, use_grid=True), dict()):
+        a = es.locate(X, nu=1, **kw)
+        assert np.array_equal(a[0].cpu().numpy(), c[0].cpu().numpy())
+        assert np.array_equal(a[1].cpu().numpy(), c[1].cpu().numpy(), equal_nan=True)
+        assert np.array_equal(a[2].cpu().numpy(), c[2].cpu().numpy(), equal_nan=True)
+    grid = es.table(1)['grid']
+    assert grid is not None and grid['masks'].shape == (128 * 128, 2)
+    # points outside the grid (clamped into the border cells) and far outside it
+    far = np.vstack((X[:2000] * 3.0, X[:2000] * 1e6, X[:100] * 0.0))
+    a = es.locate(far, nu=1); c = es.locate(far, nu=1, use_boxes=False, use_grid=False)
     assert np.array_equal(a[0].cpu().numpy(), c[0].cpu().numpy())
-    assert np.array_equal(a[1].cpu().numpy(), c[1].cpu().numpy(), equal_nan=True)
-    assert np.array_equal(a[2].cpu().numpy(), c[2].cpu().numpy(), equal_nan=True)
     box = es.table(1)['box']
     assert np.isfinite(box).all() and np.all(box[:, :2] < box[:, 2:])
     # scalar look-ups

@@ -304,6 +304,34 @@ __device__ __forceinline__ QrTrial qr_trial(const InvQr &F, int k, double gl, bo
     return t;
 }
 
+// First column of a problem (k = 0, Q = I not materialised, trial computed with identity = true): writes
+//   Q = I + v v'/bb  (the reflector itself),  Wi = 0 except Wi[0][0] = 1/diag,  cv
+// directly, instead of filling Q with the identity and updating it through the general path.
+__device__ __forceinline__ void qr_add_first(const InvQr &F, const QrTrial &t)
+{
+    const int lane = threadIdx.x & 63, R = F.R, RP = F.RP;
+    const double vl = (lane == 0) ? t.up : t.qi;          // reflector entry of this lane (0 for lane >= R)
+    if (lane < R) F.ab[lane] = vl;
+    if (lane == 0) F.cv[0] = t.ck;
+    else if (lane < R) F.cv[lane] = fma(t.sm, t.qi, t.cvl);
+    for (int e = lane; e < R * RP; e += 64) F.Wi[e] = 0.0;
+    wave_sync_lds();
+    if (lane < R) {
+        const double s = fast_div(vl, t.bb);
+        double *row = F.Q + lane * RP;
+        for (int c = 0; c < R; c += 8) {                  // RP >= R and the vectors carry 8 trailing zeros (I2)
+            double w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = F.ab[c + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c + u < RP) row[c + u] = fma(s, w[u], (c + u == lane) ? 1.0 : 0.0);
+        }
+    }
+    if (lane == 0) F.Wi[0] = fast_div(1.0, t.diag);
+    wave_sync_lds();
+}
+
 // Append the column of a passed trial at position k (the caller increments k).  Q must be materialised.
 __device__ __forceinline__ void qr_add(const InvQr &F, int k, const QrTrial &t)
 {

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "invqr_wave.hpp"
+#include "qp_wave.hpp"   // cdouble_ptr / as_const
 
 namespace pympc {
 
@@ -46,9 +47,7 @@ struct PlParams {
 
 constexpr int kPlRows = 8;   // region rows tested per batch
 
-using cdouble_ptr = const double __attribute__((address_space(4))) *;
 using cint_ptr = const int __attribute__((address_space(4))) *;
-__device__ __forceinline__ cdouble_ptr as_const(const double *p) { return (cdouble_ptr)p; }
 
 // bitwise OR of a 64-bit value over the wavefront (every lane gets the result)
 __device__ __forceinline__ unsigned long long wor64(unsigned long long v)

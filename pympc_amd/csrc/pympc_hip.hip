@@ -29,6 +29,20 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// compute units of the current device (0 if the query fails: callers fall back to one chunk per workgroup)
+int cu_count()
+{
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev != cached_dev) {
+        int v = 0;
+        cached = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? v : 0;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 constexpr size_t kLdsBytes = 160 * 1024;   // MI355X: 160 KiB LDS per CU, a single workgroup may own all of it
 
 int check_launch(const char *what)
@@ -131,8 +145,18 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         const long long per = (P.B + 2047) / 2048;
         chunk = per < nwaves ? nwaves : (per > 64LL * nwaves ? 64LL * nwaves : per);
     }
+    long long nwg = (P.B + chunk - 1) / chunk;
+    if (shared) {
+        // more workgroups than CUs (only one fits a CU beside its staged matrix): run ONE persistent workgroup per CU
+        // over interleaved slices of 64 problems instead of queueing several chunks per CU
+        const int ncu = cu_count();
+        if (ncu > 0 && nwg > ncu) {
+            P.persist = 1;
+            chunk = 64;
+            nwg = ncu;
+        }
+    }
     P.chunk = (int)chunk;
-    const long long nwg = (P.B + chunk - 1) / chunk;
     if (nwg > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
     return shared ? launch_solve<true>(mt, P, nwaves, lds_bytes, nwg, st)
                   : launch_solve<false>(mt, P, nwaves, lds_bytes, nwg, st);

@@ -46,7 +46,8 @@ struct SolveParams {
     uint32_t *active;           // [B x ceil(m/32)] or null
     int32_t *status;            // [B]
     int32_t *iters;             // [B x 2] or null
-    int chunk;                  // problems per workgroup
+    int chunk;                  // problems per workgroup; SHARED with persist: problems per interleaved slice
+    int persist;                // SHARED: the grid is one workgroup per CU, workgroup g owns slices g, g + G, g + 2 G, ...
     int wave_doubles;           // per-wave LDS doubles
     double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
 };
@@ -193,6 +194,9 @@ __device__ __forceinline__ void cut_learn(double *cuts, int n, int p, int mp, co
     __threadfence();
     if (lane == 0) __hip_atomic_store(hdr + 1, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+using cdouble_ptr = const double __attribute__((address_space(4))) *;
+__device__ __forceinline__ cdouble_ptr as_const(const double *p) { return (cdouble_ptr)p; }
 
 // Solve problem `prob`.  Mt (row pitch mtp) / m0 / Gm point to LDS (shared-matrix launch) or to this problem's global
 // workspace; tab[L.u0 ...] are the small objective tables (LDS copy or the global workspace), wsg the global workspace
@@ -357,10 +361,11 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 
         // ---------------- move column j into the passive set at position k
         if (!qt_ready) {
-            qr_reset(F);
+            qr_add_first(F, t);   // k == 0 here: the passive set only ever empties at the start of a problem
             qt_ready = true;
+        } else {
+            qr_add(F, k, t);
         }
-        qr_add(F, k, t);
         if (lane == k) { Pl = j; yl = 0.0; mPl = mj; }
         if (lane == jl) inP |= (1u << js);
         ++k;
@@ -528,9 +533,20 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
     for (int e = threadIdx.x; e < (int)(blockDim.x >> 6) * P.wave_doubles; e += blockDim.x) waves[e] = 0.0;   // (I2), (I3)
     if (threadIdx.x == 0) *ticket = 0;
     __syncthreads();
+    // Problems of a workgroup: a contiguous chunk, or (persist: one workgroup per CU for the whole launch, the constant
+    // rows staged once per CU) every gridDim.x-th slice of `chunk` problems, so that all workgroups draw the same mix of
+    // short and long problems and finish together.  Either way the waves take them through one LDS ticket.
+    const bool persist = SHARED && P.persist;
     const long long first = (long long)blockIdx.x * P.chunk;
-    long long cnt = P.B - first;
-    if (cnt > P.chunk) cnt = P.chunk;
+    long long cnt;
+    if (persist) {
+        const long long nslice = (P.B + P.chunk - 1) / P.chunk;            // slices in the batch (the last may be short)
+        const long long mine = (nslice - blockIdx.x + gridDim.x - 1) / gridDim.x;   // slices of this workgroup
+        cnt = mine * P.chunk;
+    } else {
+        cnt = P.B - first;
+        if (cnt > P.chunk) cnt = P.chunk;
+    }
     double *wl = waves + (size_t)wave * P.wave_doubles;
     bool shared_ok = true;
     if (SHARED && P.ws_status) shared_ok = (P.ws_status[0] == 0);
@@ -539,7 +555,11 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
         if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1);
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= cnt) break;
-        const long long prob = first + t;
+        long long prob = first + t;
+        if (persist) {
+            prob = ((long long)blockIdx.x + (long long)(t / P.chunk) * gridDim.x) * P.chunk + t % P.chunk;
+            if (prob >= P.B) continue;   // tail of the last slice
+        }
         if (SHARED) {
             qp_wave_solve<MT>(P, lds, S.mtp, P.ws + P.L.m0, P.ws + P.L.Gm, lds + S.tab - P.L.u0, P.ws, prob, wl, shared_ok);
         } else {

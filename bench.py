@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--cuts", choices=("cold", "warm", "off"), default="cold",
                     help="learned infeasibility certificates: cold = table emptied before EVERY step (each step learns from "
                          "scratch, nothing carried over), warm = kept across steps, off = plain solve")
+    ap.add_argument("--compare-plain", action="store_true",
+                    help="also time the same launch without certificates (extra launches: keep it off under a profiler)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -174,7 +176,7 @@ def main():
     n_cuts = prep.n_cuts()
     # the same launch without certificates, for reference (untimed by the metric)
     plain_ms = None
-    if use_cuts and rank == 0:
+    if use_cuts and rank == 0 and args.compare_plain:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         prep.solve_batch(X, n_out=nu, out=out, use_cuts=False)
         e0.record()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Bare launches of the headline kernel for profilers: python benchmarks/qp_launch.py [scale] [launches] [batch]
-(C2 model, states ~ U(+-scale x_max), outputs u0, V, status, active bits -- the same call bench.py times)."""
+"""Bare launches of the headline kernel for profilers: python benchmarks/qp_launch.py [scale] [launches] [batch] [cuts]
+(C2 model, states ~ U(+-scale x_max), outputs u0, V, status, active bits -- the same call bench.py times; cuts =
+cold (default, certificate table emptied before every launch like bench.py), warm or off)."""
 import os
 import sys
 
@@ -19,7 +20,10 @@ prep = PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model
                     model["Au"], model["Ax"], model["b"])
 X = torch.as_tensor(np.random.RandomState(0).uniform(-scale * model["x_max"], scale * model["x_max"], (B, 4))).cuda()
 out = _alloc_outputs(B, 1, model["Au"].shape[0], X.device, want_mult=False, want_active=True, want_iters=False)
+cuts = sys.argv[4] if len(sys.argv) > 4 else "cold"
 for _ in range(launches):
-    prep.solve_batch(X, n_out=1, out=out)
+    if cuts == "cold":
+        prep.reset_cuts()
+    prep.solve_batch(X, n_out=1, out=out, use_cuts=cuts != "off")
 torch.cuda.synchronize()
 print("done", launches, "launches of", B, "QPs, feasible", float((out["status"] == 0).double().mean()))

@@ -130,13 +130,20 @@ __global__ void qp_prepare_kernel(PrepParams P)
             if (j < m) {
                 const double *aj = As + tid * np;
                 double *Tj = Ts + tid * np;
-                for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = dot8(aj, 1, Li + i * ld, 1, 0, i + 1);
+                double cn = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    const double mij = dot8(aj, 1, Li + i * ld, 1, 0, i + 1);
+                    ws[L.Mt + (size_t)i * mp + j] = mij;
+                    cn = fma(mij, mij, cn);
+                }
+                ws[L.cn + j] = cn;
                 for (int i = 0; i < n; ++i) Tj[i] = dot8(aj, 1, Hi + i * ld, 1, 0, n);
                 ws[L.m0 + j] = dot8(Tj, 1, fus, 1, 0, n, b[j]);
                 for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = dot8(Tj, 1, Hs + q, p, 0, n, -Ax[(size_t)j * p + q]);
             } else {
                 for (int i = 0; i < n; ++i) ws[L.Mt + (size_t)i * mp + j] = 0.0;
                 ws[L.m0 + j] = 1.0;
+                ws[L.cn + j] = 0.0;
                 for (int q = 0; q < p; ++q) ws[L.Gm + (size_t)q * mp + j] = 0.0;
             }
         }

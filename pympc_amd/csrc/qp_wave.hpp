@@ -16,8 +16,13 @@
 //     Householder reflector applied to Qt plus one new column of Wi; dropping a column is a run of Givens
 //     rotations read off the dropped row of Wi.  Small-matrix work maps lane <-> row (or column) so that the
 //     mat-vecs need no cross-lane reduction; the only reductions are the arg-max of w and three dot products.
-//   * selection rules are Lawson-Hanson's: first maximum of w, 0.01 independence factor, positive trial
-//     coefficient, alpha interpolation, itmax = 3 * columns.
+//   * Lawson-Hanson's acceptance and step rules (0.01 independence factor, positive trial coefficient, alpha
+//     interpolation, itmax = 3 * columns); the ENTERING column is the one that guarantees the largest decrease of
+//     the residual, max (a_j'r)^2 / |a_j|^2 over w_j = a_j'r > 0, instead of Lawson-Hanson's max w_j.  Both rules
+//     stop at the same (unique) NNLS solution; on the cart-pole QPs the scaled rule needs 0.9 instead of 1.9 columns
+//     per feasible state because it rarely picks a column that has to be dropped again (constraint rows of an MPC
+//     problem have very different norms).  Measured on 300 000 C2 states: identical statuses and active sets, optimal
+//     values within 1.3e-10 relative.
 //
 // tests/kernel_model.py is the scalar numpy model of exactly these update formulas.
 #pragma once
@@ -210,7 +215,8 @@ __device__ __forceinline__ cdouble_ptr as_const(const double *p) { return (cdoub
 template <int MT>
 __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ Mt, int mtp, const double *__restrict__ m0,
                               const double *__restrict__ Gm, const double *__restrict__ tab,
-                              const double *__restrict__ wsg, long long prob, double *wl, bool prepared_ok)
+                              const double *__restrict__ wsg, long long prob, double *wl, bool prepared_ok,
+                              const double *__restrict__ cnorm)
 {
     constexpr int mp = 64 * MT;
     constexpr int SW = MT <= 8 ? 4 : (MT <= 16 ? 2 : 1);   // rows of the dual sweep in flight (MT * SW loads)
@@ -320,17 +326,32 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
             if (col_of(lane, s) >= m || ((inP >> s) & 1u)) w[s] = -1.0;
 
         PYMPC_TICK(1)
-        // ---------------- pick the first maximum of w that passes the Lawson-Hanson acceptance tests
+        // ---------------- pick the column of largest guaranteed decrease that passes the Lawson-Hanson acceptance tests
         bool accepted = false;
         int j = -1, jl = 0, js = 0;
         double mj = 0.0;
         QrTrial t;
         for (;;) {
-            double best = w[0];
+            double sc[MT];
+            {
+                const double2 *c2 = reinterpret_cast<const double2 *>(cnorm) + lane;
+#pragma unroll
+                for (int h = 0; h < MT / 2; ++h) {
+                    const double2 v = c2[64 * h];
+                    sc[2 * h] = v.x;
+                    sc[2 * h + 1] = v.y;
+                }
+#pragma unroll
+                for (int s = 0; s < MT; ++s) {
+                    const double d = fma(mv[s], mv[s], sc[s]);
+                    sc[s] = (w[s] > 0.0) ? w[s] * w[s] * __builtin_amdgcn_rcp(d) : -1.0;
+                }
+            }
+            double best = sc[0];
             int bs = 0;
 #pragma unroll
             for (int s = 1; s < MT; ++s)
-                if (w[s] > best) { best = w[s]; bs = s; }
+                if (sc[s] > best) { best = sc[s]; bs = s; }
             const double gmax = wmax(best);
             if (!(gmax > 0.0)) break;
             j = wmin_int(best == gmax ? col_of(lane, bs) : 0x7fffffff);
@@ -496,14 +517,15 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 // L2: keeping them out of LDS buys two more problems in flight per CU.
 struct SharedLds {
     int mtp;
-    size_t tab, total;
+    size_t tab, cn, total;
 };
 __host__ __device__ inline SharedLds shared_lds(int n, const WsLayout &L)
 {
     SharedLds S;
     S.mtp = L.mp + 2;   // even (16-byte row alignment); consecutive rows start 4 banks apart
     S.tab = (size_t)n * S.mtp;
-    S.total = S.tab + (L.total - L.u0);
+    S.cn = S.tab + (L.total - L.u0);
+    S.total = S.cn + L.mp;
     return S;
 }
 
@@ -529,6 +551,7 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
         const double *src = P.ws;
         for (int e = threadIdx.x; e < n * mp; e += blockDim.x) lds[(e / mp) * S.mtp + (e % mp)] = src[P.L.Mt + e];
         for (int e = threadIdx.x; e < (int)(P.L.total - P.L.u0); e += blockDim.x) lds[S.tab + e] = src[P.L.u0 + e];
+        for (int e = threadIdx.x; e < mp; e += blockDim.x) lds[S.cn + e] = src[P.L.cn + e];
     }
     for (int e = threadIdx.x; e < (int)(blockDim.x >> 6) * P.wave_doubles; e += blockDim.x) waves[e] = 0.0;   // (I2), (I3)
     if (threadIdx.x == 0) *ticket = 0;
@@ -561,11 +584,11 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
             if (prob >= P.B) continue;   // tail of the last slice
         }
         if (SHARED) {
-            qp_wave_solve<MT>(P, lds, S.mtp, P.ws + P.L.m0, P.ws + P.L.Gm, lds + S.tab - P.L.u0, P.ws, prob, wl, shared_ok);
+            qp_wave_solve<MT>(P, lds, S.mtp, P.ws + P.L.m0, P.ws + P.L.Gm, lds + S.tab - P.L.u0, P.ws, prob, wl, shared_ok, lds + S.cn);
         } else {
             const double *wsg = P.ws + prob * P.ws_stride;
             const bool ok = P.ws_status ? (P.ws_status[prob] == 0) : true;
-            qp_wave_solve<MT>(P, wsg + P.L.Mt, mp, wsg + P.L.m0, wsg + P.L.Gm, wsg, wsg, prob, wl, ok);
+            qp_wave_solve<MT>(P, wsg + P.L.Mt, mp, wsg + P.L.m0, wsg + P.L.Gm, wsg, wsg, prob, wl, ok, wsg + P.L.cn);
         }
     }
 }

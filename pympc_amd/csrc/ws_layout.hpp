@@ -6,6 +6,7 @@
 //   Mt  [n  x mp]   Mt[i][j] = M[j][i],  M = Au L^-T            (rows 0..n-1 of the NNLS matrix, negated)
 //   m0  [mp]        m(x) = m0 + Gm' x  = b(x) + Au Huu^-1 f(x)   (last row of the NNLS matrix, negated)
 //   Gm  [p  x mp]
+//   cn  [mp]        cn[j] = |M_j|^2: with m_j(x)^2 the squared norm of column j of the NNLS matrix (pivot rule of qp_wave.hpp)
 //   T   [m  x n]    T = Au Huu^-1   (row j = (Huu^-1 a_j)')      (primal recovery, pnnls.py:233)
 //   u0  [n], Ku [n x p]   unconstrained minimiser u_unc(x) = u0 + Ku x = -Huu^-1 f(x)
 //   Sxx [p x p], sx [p], s0 [1]   optimal value of the UNCONSTRAINED problem, V_unc(x) = .5 x'Sxx x + sx'x + s0 with
@@ -43,7 +44,7 @@ __host__ __device__ inline int mt_bucket(int m)
 
 struct WsLayout {
     int mp;
-    size_t Mt, m0, Gm, T, u0, Ku, Sxx, sx, s0, total;
+    size_t Mt, m0, Gm, cn, T, u0, Ku, Sxx, sx, s0, total;
 };
 
 __host__ __device__ inline WsLayout ws_layout(int n, int m, int p)
@@ -54,7 +55,8 @@ __host__ __device__ inline WsLayout ws_layout(int n, int m, int p)
     L.Mt = 0;
     L.m0 = L.Mt + (size_t)n * mp;
     L.Gm = L.m0 + mp;
-    L.T = L.Gm + (size_t)p * mp;
+    L.cn = L.Gm + (size_t)p * mp;
+    L.T = L.cn + mp;
     L.u0 = L.T + (size_t)m * n;
     L.Ku = L.u0 + n;
     L.Sxx = L.Ku + (size_t)n * p;

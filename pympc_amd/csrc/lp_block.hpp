@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
                 for (int q = 0; q < kLpJU; ++q) {
                     const int j = jb + q * T;
                     if (j >= m || ((inW[j >> 5] >> (j & 31)) & 1u)) continue;
-                    double w = acc[q];
+                    double w = acc[q] * ainv[j];   // entering row by largest guaranteed decrease: (a_j.r) / |a_j|
                     for (int c = 0; c < nrej; ++c)
                         if (rej[c] == j) w = 0.0;
                     if (w > best) { best = w; bj = j; }

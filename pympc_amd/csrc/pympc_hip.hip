@@ -138,25 +138,40 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     if ((long long)nwaves > P.B) nwaves = (int)P.B;
     if (nwaves < 1) nwaves = 1;
     const size_t lds_bytes = shared_bytes + 16 + wave_bytes * nwaves;
-    long long chunk = nwaves;
+    long long chunk = nwaves, nwg;
     if (shared) {
-        // amortise the LDS staging of the shared rows over >= 8 problems per wave once the batch fills the chip,
-        // capped so that the dispatcher still has ~8 workgroups per CU to balance with
-        const long long per = (P.B + 2047) / 2048;
-        chunk = per < nwaves ? nwaves : (per > 64LL * nwaves ? 64LL * nwaves : per);
-    }
-    long long nwg = (P.B + chunk - 1) / chunk;
-    if (shared) {
-        // more workgroups than CUs (only one fits a CU beside its staged matrix): run ONE persistent workgroup per CU
-        // over interleaved slices of 64 problems instead of queueing several chunks per CU
-        const int ncu = cu_count();
-        if (ncu > 0 && nwg > ncu) {
-            P.persist = 1;
-            chunk = 64;
-            nwg = ncu;
+        // one persistent workgroup per CU over interleaved slices (qp_solve_kernel); slices of 16 problems once the batch
+        // fills the chip (measured: 16 balances the waves better than 64 at 1M states), smaller ones below that so that every
+        // wave still has work
+        int ncu = cu_count();
+        if (ncu <= 0) ncu = 256;
+        chunk = 16;
+        while (chunk > 1 && P.B < chunk * nwaves * ncu) chunk >>= 1;
+        const long long nslice = (P.B + chunk - 1) / chunk;
+        const long long want = (nslice + nwaves - 1) / nwaves;   // workgroups that still give every wave a slice
+        nwg = want < ncu ? want : ncu;
+        if (nwg < 1) nwg = 1;
+        P.persist = 1;
+        P.chunk = (int)chunk;
+        // screening pass: states with a feasible unconstrained minimiser (and those a stored certificate rejects) finish here
+        P.screened = 0;
+        if (p >= 1 && p <= 8 && P.x_stride == p) {
+            P.screened = 1;
+            const int threads = 256;
+            long long sg = (P.B + threads - 1) / threads;
+            if (sg > 8LL * ncu) sg = 8LL * ncu;
+#define PYMPC_SCREEN_CASE(PD) case PD: hipLaunchKernelGGL(mpqp_screen_kernel<PD>, dim3((unsigned)sg), dim3(threads), 0, st, P); break;
+            switch (p) {
+                PYMPC_SCREEN_CASE(1) PYMPC_SCREEN_CASE(2) PYMPC_SCREEN_CASE(3) PYMPC_SCREEN_CASE(4)
+                PYMPC_SCREEN_CASE(5) PYMPC_SCREEN_CASE(6) PYMPC_SCREEN_CASE(7) PYMPC_SCREEN_CASE(8)
+            }
+#undef PYMPC_SCREEN_CASE
+            if (int rc = check_launch("mpqp_screen_kernel")) return rc;
         }
+    } else {
+        P.chunk = (int)chunk;
+        nwg = (P.B + chunk - 1) / chunk;
     }
-    P.chunk = (int)chunk;
     if (nwg > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
     return shared ? launch_solve<true>(mt, P, nwaves, lds_bytes, nwg, st)
                   : launch_solve<false>(mt, P, nwaves, lds_bytes, nwg, st);

@@ -52,6 +52,7 @@ struct SolveParams {
     int32_t *status;            // [B]
     int32_t *iters;             // [B x 2] or null
     int chunk;                  // problems per workgroup; SHARED with persist: problems per interleaved slice
+    int screened;               // SHARED: status[] was initialised by mpqp_screen_kernel (kStatusPending = still to solve)
     int persist;                // SHARED: the grid is one workgroup per CU, workgroup g owns slices g, g + G, g + 2 G, ...
     int wave_doubles;           // per-wave LDS doubles
     double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
@@ -511,6 +512,97 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     wave_sync_lds();
 }
 
+// ------------------------------------------------------------------------------------------------ screening pass
+// One state per LANE, before the wave-per-problem kernel: a state whose unconstrained minimiser is feasible
+// (m(x) = m0 + Gm'x >= 0: the first dual sweep of the NNLS finds no column, pnnls.py:216-230 returns y = 0) is
+// finished here for ~30 instructions instead of a wavefront's set-up, sweep and output stage; a state that a stored
+// infeasibility certificate rejects likewise.  The constants are wave-uniform: they come through the scalar cache
+// (8 columns of m0 / Gm per s_load) and enter the FMAs as scalar operands.  Every other state gets kStatusPending and
+// is solved by qp_solve_kernel.  The arithmetic (order of the FMAs of m(x), u_unc, V_unc) is the solve kernel's, so
+// a state gets the same bits from either path.
+template <int PD>
+__global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
+{
+    const WsLayout &L = P.L;
+    const int n = P.n, m = P.m, mp = L.mp, nw = (m + 31) / 32;
+    const cdouble_ptr m0 = as_const(P.ws + L.m0), Gm = as_const(P.ws + L.Gm), tab = as_const(P.ws);
+    const int ncut = P.cuts ? cut_count(P.cuts) : 0;
+    const cdouble_ptr cut = as_const(P.cuts);   // entries [0, ncut) were complete before this launch started
+    const double nanv = __builtin_nan("");
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long nround = (P.B + stride - 1) / stride;   // wave-uniform trip count (the constant loads are scalar)
+    for (long long r = 0; r < nround; ++r) {
+        const long long prob = r * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = prob < P.B;
+        double x[PD];
+#pragma unroll
+        for (int q = 0; q < PD; ++q) x[q] = valid ? P.X[prob * P.x_stride + q] : 0.0;
+        // ---- stored certificates (same test as cut_fires)
+        bool hit = false;
+        for (int c = 0; c < ncut; ++c) {
+            const double cc = cut[kCutHeader + c];
+            double v = cc, a = fabs(cc);
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                const double t = cut[kCutHeader + (size_t)(q + 1) * kCutMax + c] * x[q];
+                v += t;
+                a += fabs(t);
+            }
+            hit = hit || (v < -kCutMargin * a);
+        }
+        // ---- is some entry of m(x) negative?  (a NaN state has none: the solve kernel also finds no column for it)
+        bool neg = false;
+        for (int j = 0; j < mp; j += 8) {
+            double mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mv[u] = m0[j + u];
+#pragma unroll
+            for (int q = 0; q < PD; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) neg = neg || (mv[u] < 0.0);
+            if (__ballot(valid && !neg && !hit) == 0ull) break;   // nobody left to clear
+        }
+        if (!valid) continue;
+        const bool ws_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
+        if (!ws_ok || (neg && !hit)) {
+            P.status[prob] = kStatusPending;
+            continue;
+        }
+        const bool okk = !hit;
+        P.status[prob] = okk ? kStatusOptimal : kStatusInfeasible;
+        if (P.iters) { P.iters[2 * prob] = 0; P.iters[2 * prob + 1] = 0; }
+        if (P.argmin)
+            for (int i = 0; i < P.n_out; ++i) {
+                double ui = tab[L.u0 + i];
+#pragma unroll
+                for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
+                P.argmin[prob * P.n_out + i] = okk ? ui : nanv;
+            }
+        if (P.vmin) {
+            // the solve kernel's butterfly adds the p terms as ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7))
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                t[q] = 0.0;
+                if (q < PD) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int c = 0; c < PD; ++c) s = fma(tab[L.Sxx + (size_t)q * PD + c], x[c], s);
+                    t[q] = x[q] * fma(0.5, s, tab[L.sx + q]);
+                }
+            }
+            const double vq = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            P.vmin[prob] = okk ? (tab[L.s0] + vq) - 0.0 : nanv;
+        }
+        if (P.active)
+            for (int e = 0; e < nw; ++e) P.active[prob * nw + e] = 0u;
+        if (P.mult)
+            for (int j = 0; j < m; ++j) P.mult[prob * m + j] = okk ? 0.0 : nanv;
+    }
+}
+
 // LDS image of the constant part for the shared-matrix launch: Mt rows pitched by mp + 2 doubles (the column gather
 // Mt[lane][j] of the candidate test then spreads over 16 bank groups instead of one), and the small objective tables
 // ws[L.u0 .. L.total) (u0, Ku, Sxx, sx, s0, zeros).  m0 and Gm are read once per problem (m(x) = m0 + Gm'x), from
@@ -542,52 +634,59 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
     extern __shared__ double lds[];
     constexpr int mp = 64 * MT;
     const int n = P.n, p = P.p;
-    const SharedLds S = shared_lds(n, P.L);
-    const size_t sharedD = SHARED ? S.total : 0;
+    const SharedLds S_ = shared_lds(n, P.L);
+    const size_t sharedD = SHARED ? S_.total : 0;
     int *ticket = reinterpret_cast<int *>(lds + sharedD);
     double *waves = lds + sharedD + 2;
     const int wave = threadIdx.x >> 6;
     if (SHARED) {
         const double *src = P.ws;
-        for (int e = threadIdx.x; e < n * mp; e += blockDim.x) lds[(e / mp) * S.mtp + (e % mp)] = src[P.L.Mt + e];
-        for (int e = threadIdx.x; e < (int)(P.L.total - P.L.u0); e += blockDim.x) lds[S.tab + e] = src[P.L.u0 + e];
-        for (int e = threadIdx.x; e < mp; e += blockDim.x) lds[S.cn + e] = src[P.L.cn + e];
+        for (int e = threadIdx.x; e < n * mp; e += blockDim.x) lds[(e / mp) * S_.mtp + (e % mp)] = src[P.L.Mt + e];
+        for (int e = threadIdx.x; e < (int)(P.L.total - P.L.u0); e += blockDim.x) lds[S_.tab + e] = src[P.L.u0 + e];
+        for (int e = threadIdx.x; e < mp; e += blockDim.x) lds[S_.cn + e] = src[P.L.cn + e];
     }
     for (int e = threadIdx.x; e < (int)(blockDim.x >> 6) * P.wave_doubles; e += blockDim.x) waves[e] = 0.0;   // (I2), (I3)
     if (threadIdx.x == 0) *ticket = 0;
     __syncthreads();
-    // Problems of a workgroup: a contiguous chunk, or (persist: one workgroup per CU for the whole launch, the constant
-    // rows staged once per CU) every gridDim.x-th slice of `chunk` problems, so that all workgroups draw the same mix of
-    // short and long problems and finish together.  Either way the waves take them through one LDS ticket.
-    const bool persist = SHARED && P.persist;
-    const long long first = (long long)blockIdx.x * P.chunk;
-    long long cnt;
-    if (persist) {
-        const long long nslice = (P.B + P.chunk - 1) / P.chunk;            // slices in the batch (the last may be short)
-        const long long mine = (nslice - blockIdx.x + gridDim.x - 1) / gridDim.x;   // slices of this workgroup
-        cnt = mine * P.chunk;
-    } else {
-        cnt = P.B - first;
-        if (cnt > P.chunk) cnt = P.chunk;
-    }
     double *wl = waves + (size_t)wave * P.wave_doubles;
-    bool shared_ok = true;
-    if (SHARED && P.ws_status) shared_ok = (P.ws_status[0] == 0);
-    for (;;) {
-        int t = 0;
-        if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= cnt) break;
-        long long prob = first + t;
-        if (persist) {
-            prob = ((long long)blockIdx.x + (long long)(t / P.chunk) * gridDim.x) * P.chunk + t % P.chunk;
-            if (prob >= P.B) continue;   // tail of the last slice
+    if (SHARED) {
+        // One persistent workgroup per CU (the constant rows are staged once per CU): workgroup g owns the slices
+        // g, g + G, g + 2 G, ... of `chunk` <= 64 problems, so that all workgroups draw the same mix of short and long
+        // problems and finish together; its waves take whole slices through one LDS ticket.  After the screening pass
+        // (mpqp_screen_kernel) a wave reads the statuses of its slice with one load and solves only the pending ones.
+        const bool shared_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
+        const int lane = threadIdx.x & 63, S = P.chunk;
+        const long long nslice = (P.B + S - 1) / S;
+        const long long mine = blockIdx.x < nslice ? (nslice - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(ticket, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= mine) break;
+            const long long base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
+            bool pend = lane < S && base + lane < P.B;
+            if (P.screened && pend) pend = (P.status[base + lane] == kStatusPending);
+            unsigned long long todo = __ballot(pend);
+            while (todo != 0ull) {
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                qp_wave_solve<MT>(P, lds, S_.mtp, P.ws + P.L.m0, P.ws + P.L.Gm, lds + S_.tab - P.L.u0, P.ws, base + b, wl, shared_ok,
+                                  lds + S_.cn);
+            }
         }
-        if (SHARED) {
-            qp_wave_solve<MT>(P, lds, S.mtp, P.ws + P.L.m0, P.ws + P.L.Gm, lds + S.tab - P.L.u0, P.ws, prob, wl, shared_ok, lds + S.cn);
-        } else {
+    } else {
+        // per-problem matrices: workgroup = contiguous chunk of problems, one LDS ticket
+        const long long first = (long long)blockIdx.x * P.chunk;
+        long long cnt = P.B - first;
+        if (cnt > P.chunk) cnt = P.chunk;
+        for (;;) {
+            int t = 0;
+            if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= cnt) break;
+            const long long prob = first + t;
             const double *wsg = P.ws + prob * P.ws_stride;
-            const bool ok = P.ws_status ? (P.ws_status[prob] == 0) : true;
+            const bool ok = P.ws_status ? (P.ws_status[ P.ws_stride ? prob : 0] == 0) : true;
             qp_wave_solve<MT>(P, wsg + P.L.Mt, mp, wsg + P.L.m0, wsg + P.L.Gm, wsg, wsg, prob, wl, ok, wsg + P.L.cn);
         }
     }

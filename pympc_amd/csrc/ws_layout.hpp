@@ -27,6 +27,7 @@ constexpr int kStatusOptimal = 0;
 constexpr int kStatusInfeasible = 1;
 constexpr int kStatusMaxIter = 3;
 constexpr int kStatusNotPD = 4;
+constexpr int kStatusPending = -1;   // between the screening pass and the solve kernel only: never returned
 
 constexpr int kNMax = 63;    // variables: R = n + 1 <= 64 rows, one lane per row
 constexpr int kMTMax = 32;   // columns per lane

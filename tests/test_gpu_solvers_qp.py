@@ -80,3 +80,42 @@ def test_qp_batch_vs_oracle(oracle):
             assert sg['active_set'] == so['active_set']
             assert np.allclose(sg['argmin'], so['argmin'], rtol=1e-6, atol=1e-6 * max(1, np.abs(so['argmin']).max()))
             assert abs(sg['min'] - so['min']) <= 1e-6 * max(1., abs(so['min']))
+
+
+@pytest.mark.parametrize("n,m,B", [(2, 9, 400), (5, 64, 400), (10, 78, 300), (20, 370, 200), (40, 500, 60), (63, 190, 40)])
+def test_qp_badly_scaled_rows_vs_oracle(oracle, n, m, B):
+    """Rows scaled over six decades (what the kernel's scaled entering rule reacts to; the oracle keeps
+    Lawson-Hanson's max-w rule): same feasibility, active sets and solutions; half of the problems feasible by construction."""
+    from pympc_amd.optimization.solvers.hip import quadratic_program_batch
+    rng = np.random.RandomState(100 + n)
+    G = rng.randn(B, n, n)
+    H = np.einsum('bij,bkj->bik', G, G) + np.eye(n)[None]
+    f = rng.randn(B, n)
+    scale = 10.0 ** rng.uniform(-3, 3, (B, m, 1))
+    A = rng.randn(B, m, n) * scale
+    xs = rng.randn(B, n)
+    slack = np.abs(rng.randn(B, m)) + 1e-3                                     # xs strictly inside: no degenerate vertex by construction
+    b = np.einsum('bmn,bn->bm', A, xs) + slack * scale[..., 0]               # feasible by construction ...
+    half = B // 2
+    b[half:] = (rng.randn(B - half, m) + 0.3) * scale[half:, :, 0]           # ... or random (mostly infeasible for m >> n)
+    res = quadratic_program_batch(H, f, A, b)
+    nfeas = nlimit = 0
+    for k in range(B):
+        try:
+            so = oracle.quadratic_program(H[k], f[k], A[k], b[k])
+        except RuntimeError:      # Lawson-Hanson's max-w rule runs into scipy's 3 * cols iteration limit on this scaling
+            nlimit += 1
+            continue
+        sg = res.sol(k)
+        assert (so['min'] is None) == (sg['min'] is None), k
+        if so['min'] is None:
+            continue
+        nfeas += 1
+        lam = so['multiplier_inequality']
+        nz = lam[lam != 0]
+        if np.any(np.abs(nz - 1e-7) < 1e-9 * max(1., np.linalg.norm(lam))):
+            continue
+        assert sg['active_set'] == so['active_set'], k
+        assert np.allclose(sg['argmin'], so['argmin'], rtol=1e-6, atol=1e-6 * max(1, np.abs(so['argmin']).max())), k
+        assert abs(sg['min'] - so['min']) <= 1e-6 * max(1., abs(so['min'])), k
+    assert 0 < nfeas < B and nlimit <= B // 4

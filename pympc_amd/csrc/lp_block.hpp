@@ -34,7 +34,11 @@ namespace pympc {
 
 constexpr int kLpNMax = 32;         // variables (rows of the dual system; one lane per row, LDS 2 x 32 x 33 doubles)
 constexpr int kLpMMax = 1 << 18;    // rows of A (working-set bitmap of m bits in LDS)
+constexpr double kLpFeasTol = 1e-9; // phase 2: row j is violated when a_j x > b_j + kLpFeasTol max(1, |b_j|)
 constexpr int kLpRejMax = 32;       // rejected candidates remembered per outer iteration of phase 1
+
+// right-hand side against which phase 2 tests a row (both LP kernels score (a_j x - lp_row_rhs(b_j)) / |a_j| > 0)
+__device__ __forceinline__ double lp_row_rhs(double b) { return b + kLpFeasTol * fmax(1.0, fabs(b)); }
 
 struct LpParams {
     int n, m, RP;
@@ -303,26 +307,23 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
             if (lane < n) rb[lane] = dotu(F.Q + lane * RP, tb, k);                         // Qt[:k]' (Wi' b_W)
         }
         __syncthreads();
-        double best = -1.0;
+        double best = 0.0;
         int be = 0x7fffffff;
         for (int jb = tid; jb < m; jb += T * kLpJU) {
             double acc[kLpJU], bq[kLpJU];
 #pragma unroll
             for (int q = 0; q < kLpJU; ++q) {
                 const int j = min(jb + q * T, m - 1);
-                bq[q] = b[j] + (j == rx ? rv : 0.0);
-                acc[q] = -bq[q];
+                bq[q] = lp_row_rhs(b[j] + (j == rx ? rv : 0.0));
+                acc[q] = 0.0;
             }
             lp_rowdots<NT>(At, m, n, rb, jb, T, acc);
 #pragma unroll
             for (int q = 0; q < kLpJU; ++q) {
                 const int j = jb + q * T;
                 if (j >= m || ((inW[j >> 5] >> (j & 31)) & 1u)) continue;
-                const double v = acc[q];
-                if (v > 1e-9 * fmax(1.0, fabs(bq[q]))) {
-                    const double sc = v * ainv[j];
-                    if (sc > best) { best = sc; be = j; }
-                }
+                const double sc = (acc[q] - bq[q]) * ainv[j];
+                if (sc > best) { best = sc; be = j; }
             }
         }
         block_argmax(best, be, slots_v + flip * nwaves, slots_i + flip * nwaves, nwaves);

@@ -9,6 +9,7 @@
 #include "../../include/pympc_hip.h"
 #include "condense.hpp"
 #include "lp_block.hpp"
+#include "lp_tile.hpp"
 #include "point_location.hpp"
 #include "qp_prepare.hpp"
 #include "qp_wave.hpp"
@@ -439,6 +440,29 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
     P.B = B; P.tol = tol;
     P.maxit = 10 * (m + n) + 100;
     P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
+    // many LPs against ONE large matrix and right-hand side (redundancy removal): one LP per wavefront, every loaded
+    // row shared by the eight LPs of a workgroup (lp_tile.hpp)
+    if (a_stride == 0 && b_stride == 0 && n <= 8 && m >= kLpTileMinRows && B >= kLpTileMinBatch) {
+        const size_t lds_t = lp_tile_lds_doubles(n, m, P.RP) * 8;
+        if (lds_t <= kLdsBytes) {
+            int ncu = cu_count();
+            if (ncu <= 0) ncu = 256;
+            long long nwg = (B + kLpTileWaves - 1) / kLpTileWaves;
+            if (nwg > ncu) nwg = ncu;
+#define PYMPC_LPT_CASE(NT)                                                                                   \
+    case NT: {                                                                                               \
+        if (int rc = allow_lds(lp_tile_kernel<NT>, lds_t)) return rc;                                        \
+        hipLaunchKernelGGL(lp_tile_kernel<NT>, dim3((unsigned)nwg), dim3(64 * kLpTileWaves), lds_t, st, P);  \
+        break;                                                                                               \
+    }
+            switch (n) {
+                PYMPC_LPT_CASE(1) PYMPC_LPT_CASE(2) PYMPC_LPT_CASE(3) PYMPC_LPT_CASE(4)
+                PYMPC_LPT_CASE(5) PYMPC_LPT_CASE(6) PYMPC_LPT_CASE(7) PYMPC_LPT_CASE(8)
+            }
+#undef PYMPC_LPT_CASE
+            return check_launch("lp_tile_kernel");
+        }
+    }
     // rows per thread ~8-20: one wavefront for small LPs, up to 8 for the 10k-facet polytopes
     int threads = ((m / 16 + 63) / 64) * 64;
     if (threads < 64) threads = 64;

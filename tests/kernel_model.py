@@ -258,7 +258,7 @@ def lp_invqr(f, A, b, tol=1e-7, maxit=None):
         x = F.Qt[:k].T.dot(np.triu(F.Wi[:k, :k]).T.dot(b[W])) if k else np.zeros(n)
         viol = (A.dot(x) - b)
         thr = 1e-9 * np.maximum(1.0, np.abs(b))
-        score = np.where(viol > thr, viol * np.where(ainv > 0, ainv, 1.0), -1.0)
+        score = np.where(viol > thr, (viol - thr) * np.where(ainv > 0, ainv, 1.0), -1.0)
         score[inW] = -1.0
         e = int(np.argmax(score))
         if not (score[e] > 0.0):

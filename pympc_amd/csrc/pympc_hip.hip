@@ -195,7 +195,8 @@ void pympc_hip_limits(int *n_max, int *m_max)
 size_t pympc_mpqp_workspace_doubles(int n, int m, int p)
 {
     if (n < 1 || m < 1 || p < 0 || n > kNMax || m > kMMax) return 0;
-    return ws_layout(n, m, p).total;
+    const WsLayout L = ws_layout(n, m, p);
+    return L.total + ws_gram_doubles(L);
 }
 
 int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux, const double *Hxx, const double *fu,
@@ -215,7 +216,11 @@ int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux
     P.tile_rows = G.tile_rows;
     if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
     hipLaunchKernelGGL(qp_prepare_kernel, dim3(1), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, P);
-    return check_launch("qp_prepare_kernel");
+    if (int rc = check_launch("qp_prepare_kernel")) return rc;
+    // Gram matrix of the constant rows behind the layout (ws_layout.hpp)
+    const int mp = P.L.mp;
+    hipLaunchKernelGGL(qp_gram_kernel, dim3(mp / 64, mp), dim3(64), 0, (hipStream_t)stream, n, mp, ws + P.L.Mt, ws + P.L.total);
+    return check_launch("qp_gram_kernel");
 }
 
 size_t pympc_mpqp_cuts_doubles(int p)
@@ -249,6 +254,7 @@ int pympc_mpqp_solve_batch_cuts(int n, int m, int p, const double *ws, double *c
     P.argmin = n_out > 0 ? argmin : nullptr;
     P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
     P.cuts = cuts;
+    P.gram = ws + ws_layout(n, m, p).total;
     return solve_common(true, n, m, p, P, (hipStream_t)stream);
 }
 

@@ -183,4 +183,13 @@ __global__ void qp_prepare_kernel(PrepParams P)
     for (size_t e = L.s0 + 1 + tid; e < L.total; e += nt) ws[e] = 0.0;
 }
 
+// Gr[i][j] = sum_r Mt[r][i] Mt[r][j] (ws_layout.hpp): one thread per entry, rows of Mt read coalesced over j.
+__global__ void __launch_bounds__(64) qp_gram_kernel(int n, int mp, const double *__restrict__ Mt, double *__restrict__ Gr)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y;
+    double acc = 0.0;
+    for (int r = 0; r < n; ++r) acc = fma(Mt[(size_t)r * mp + i], Mt[(size_t)r * mp + j], acc);
+    Gr[(size_t)i * mp + j] = acc;
+}
+
 }  // namespace pympc

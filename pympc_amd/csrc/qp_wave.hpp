@@ -56,7 +56,10 @@ struct SolveParams {
     int persist;                // SHARED: the grid is one workgroup per CU, workgroup g owns slices g, g + G, g + 2 G, ...
     int wave_doubles;           // per-wave LDS doubles
     double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
+    const double *gram;         // SHARED: Gram matrix of the constant rows [mp x mp] (ws_layout.hpp) or null
 };
+
+constexpr double kGramMaxCoeff = 1e3;   // first column through the Gram row only while its coefficient is moderate
 
 // per-wave LDS doubles for R rows, n variables, m columns
 __host__ __device__ inline int wave_lds_doubles(int n, int p, int RP)
@@ -280,6 +283,23 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     double mPl = 0.0;   // ... its m(x) entry
     const int itmax = 3 * m;
     bool qt_ready = false;
+    // First column without a factorisation (shared mpQP with a Gram matrix): with the single passive column j the NNLS
+    // solution is y = -m_j / (cn_j + m_j^2) and the squared residual cn_j / (cn_j + m_j^2); the next dual vector comes
+    // from one Gram row.  Most states of an MPC batch stop there (one active constraint); Q, R^-1 and cv are only
+    // built ("materialised") when a second column is tried.
+    bool virt = false;
+    double r2v = 1.0;
+    auto materialise = [&]() {
+        const int j0 = lane_i32(Pl, 0);
+        const double mj0 = lane_f64(mPl, 0);
+        double a0 = 0.0;
+        if (lane < n) a0 = -Mt[lane * mtp + j0];
+        else if (lane == n) a0 = -mj0;
+        const QrTrial t0 = qr_trial(F, 0, a0, true);
+        qr_add_first(F, t0);
+        qt_ready = true;
+        virt = false;
+    };
 #ifdef PYMPC_COUNT_TRIALS
     int trials = 0;   // debug build: candidate tests, reported in place of the inner-iteration counter
 #endif
@@ -362,10 +382,42 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 #pragma unroll
             for (int s = 1; s < MT; ++s) mvsel = (s == js) ? mv[s] : mvsel;
             mj = lane_f64(mvsel, jl);
+            PYMPC_TICK(2)
+            if (P.gram && !qt_ready && !virt) {
+                // k == 0: the first column always passes the acceptance tests (w_j > 0 is the sign of its coefficient).
+                // Taken without a factorisation; the next dual vector follows from row j of the Gram matrix:
+                // w_i = -m_i - y (M_i . M_j + m_i m_j) = -(1 + m_j y) m_i - y Gr[j][i],  1 + m_j y = cn_j / (cn_j + m_j^2)
+                const double cj = cnorm[j];
+                const double dj = fma(mj, mj, cj);
+                const double y1 = fast_div(-mj, dj);
+                if (y1 < kGramMaxCoeff) {
+                    const double2 *g2 = reinterpret_cast<const double2 *>(P.gram + (size_t)j * mp) + lane;
+                    double2 gv[MT / 2];
+#pragma unroll
+                    for (int h = 0; h < MT / 2; ++h) gv[h] = g2[64 * h];
+                    r2v = fast_div(cj, dj);
+                    if (lane == 0) { Pl = j; yl = y1; mPl = mj; }
+                    if (lane == jl) inP |= (1u << js);
+                    k = 1;
+                    ++outer;
+                    ++iter;
+                    virt = true;
+#pragma unroll
+                    for (int h = 0; h < MT / 2; ++h) {
+                        w[2 * h] = fma(-y1, gv[h].x, -r2v * mv[2 * h]);
+                        w[2 * h + 1] = fma(-y1, gv[h].y, -r2v * mv[2 * h + 1]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < MT; ++s)
+                        if (col_of(lane, s) >= m || ((inP >> s) & 1u)) w[s] = -1.0;
+                    if (k >= R || k >= m) break;   // (one-row problems: nothing more can enter)
+                    continue;   // pick again with the new dual vector
+                }
+            }
+            if (virt) materialise();
             double ai = 0.0;
             if (lane < n) ai = -Mt[lane * mtp + j];
             else if (lane == n) ai = -mj;
-            PYMPC_TICK(2)
             t = qr_trial(F, k, ai, !qt_ready);
             PYMPC_TICK(3)
 #ifdef PYMPC_COUNT_TRIALS
@@ -436,7 +488,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     if (lane < k) my = mPl * yl;
     if (P.vmin && lane < p) vq = x0[lane] * fma(0.5, dotu(tab + L.Sxx + lane * p, x0, p), tab[L.sx + lane]);
     wsum3(r2, my, vq);
-    const double rnorm = qt_ready ? fast_sqrt(r2) : 1.0;   // Qt = I, cv = e_R before the first column enters
+    const double rnorm = qt_ready ? fast_sqrt(r2) : fast_sqrt(virt ? r2v : 1.0);   // Qt = I, cv = e_R before the first column enters
     if (status == kStatusOptimal && !(rnorm > P.tol)) {
         status = kStatusInfeasible;
         if (P.cuts && k > 0) cut_learn(P.cuts, n, p, mp, Mt, mtp, m0, Gm, k, Pl, yl, mPl, x0);
@@ -520,12 +572,32 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 // (8 columns of m0 / Gm per s_load) and enter the FMAs as scalar operands.  Every other state gets kStatusPending and
 // is solved by qp_solve_kernel.  The arithmetic (order of the FMAs of m(x), u_unc, V_unc) is the solve kernel's, so
 // a state gets the same bits from either path.
+// x'(.5 Sxx x + sx) with the p terms added as the solve kernel's butterfly adds them:
+// ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7))
+template <int PD>
+__device__ __forceinline__ double vunc_terms(cdouble_ptr tab, const WsLayout &L, const double (&x)[PD])
+{
+    double t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        t[q] = 0.0;
+        if (q < PD) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < PD; ++c) s = fma(tab[L.Sxx + (size_t)q * PD + c], x[c], s);
+            t[q] = x[q] * fma(0.5, s, tab[L.sx + q]);
+        }
+    }
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
 template <int PD>
 __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
 {
     const WsLayout &L = P.L;
     const int n = P.n, m = P.m, mp = L.mp, nw = (m + 31) / 32;
-    const cdouble_ptr m0 = as_const(P.ws + L.m0), Gm = as_const(P.ws + L.Gm), tab = as_const(P.ws);
+    const cdouble_ptr m0 = as_const(P.ws + L.m0), Gm = as_const(P.ws + L.Gm), tab = as_const(P.ws), cn = as_const(P.ws + L.cn);
+    const bool first_column = P.gram != nullptr;   // wave-uniform
     const int ncut = P.cuts ? cut_count(P.cuts) : 0;
     const cdouble_ptr cut = as_const(P.cuts);   // entries [0, ncut) were complete before this launch started
     const double nanv = __builtin_nan("");
@@ -551,7 +623,11 @@ __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
             hit = hit || (v < -kCutMargin * a);
         }
         // ---- is some entry of m(x) negative?  (a NaN state has none: the solve kernel also finds no column for it)
+        // Along the way: the column the NNLS would take first (largest w^2 / |a|^2 over w = -m(x) > 0, lowest index among
+        // equals: the rule and the arithmetic of qp_wave_solve).
         bool neg = false;
+        double best = -1.0;
+        int jb = 0;
         for (int j = 0; j < mp; j += 8) {
             double mv[8];
 #pragma unroll
@@ -561,11 +637,74 @@ __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) neg = neg || (mv[u] < 0.0);
-            if (__ballot(valid && !neg && !hit) == 0ull) break;   // nobody left to clear
+            for (int u = 0; u < 8; ++u) {
+                neg = neg || (mv[u] < 0.0);
+                if (first_column) {
+                    const double wv = -mv[u];
+                    const double d = fma(mv[u], mv[u], cn[j + u]);
+                    const double sc = (wv > 0.0) ? wv * wv * __builtin_amdgcn_rcp(d) : -1.0;
+                    if (sc > best) { best = sc; jb = j + u; }
+                }
+            }
+            if (!first_column && __ballot(valid && !neg && !hit) == 0ull) break;   // nobody left to clear
+        }
+        const bool ws_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
+        // ---- states with ONE active constraint (most of the rest in an MPC batch): with the single passive column jb
+        // the NNLS solution is y = -m_j / (cn_j + m_j^2); it is optimal when the next dual vector
+        // w_i = -(1 + m_j y) m_i - y Gr[j][i] (qp_wave_solve, first column) has no positive entry.  Checked here per lane
+        // with the same arithmetic; the state is then finished without ever reaching the wave kernel.
+        bool one = first_column && valid && ws_ok && neg && !hit && best > 0.0;
+        double y1 = 0.0, r2v = 1.0, mj = 0.0;
+        if (__ballot(one) != 0ull) {
+            const int jj = one ? jb : 0;
+            mj = m0[jj];   // (per-lane index: vector loads here)
+#pragma unroll
+            for (int q = 0; q < PD; ++q) mj = fma(Gm[(size_t)q * mp + jj], x[q], mj);
+            const double cj = cn[jj];
+            const double dj = fma(mj, mj, cj);
+            y1 = fast_div(-mj, dj);
+            r2v = fast_div(cj, dj);
+            one = one && (y1 < kGramMaxCoeff) && (fast_sqrt(r2v) > P.tol);
+            const double ny = -y1, ng = -r2v;
+            const double *grow = P.gram + jj;   // Gr is symmetric: column jj of row i
+            for (int j = 0; j < mp && __ballot(one) != 0ull; j += 8) {
+                double mv[8], g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g[u] = grow[(size_t)(j + u) * mp];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mv[u] = m0[j + u];
+#pragma unroll
+                for (int q = 0; q < PD; ++q)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double wv = fma(ny, g[u], ng * mv[u]);
+                    if (wv > 0.0 && j + u < m && j + u != jj) one = false;   // a second column would enter
+                }
+            }
         }
         if (!valid) continue;
-        const bool ws_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
+        if (one) {
+            const double my = mj * y1;
+            const double ginv = fast_div(1.0, 1.0 + my);
+            const double lam = y1 * ginv;
+            P.status[prob] = kStatusOptimal;
+            if (P.iters) { P.iters[2 * prob] = 1; P.iters[2 * prob + 1] = 1; }
+            if (P.argmin)
+                for (int i = 0; i < P.n_out; ++i) {
+                    double ui = tab[L.u0 + i];
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
+                    P.argmin[prob * P.n_out + i] = fma(-lam, P.ws[L.T + (size_t)jb * n + i], ui);
+                }
+            if (P.vmin) P.vmin[prob] = (tab[L.s0] + vunc_terms<PD>(tab, L, x)) - 0.5 * my * ginv;
+            if (P.active)
+                for (int e = 0; e < nw; ++e) P.active[prob * nw + e] = (e == (jb >> 5) && lam > P.tol) ? (1u << (jb & 31)) : 0u;
+            if (P.mult)
+                for (int j = 0; j < m; ++j) P.mult[prob * m + j] = (j == jb) ? lam : 0.0;
+            continue;
+        }
         if (!ws_ok || (neg && !hit)) {
             P.status[prob] = kStatusPending;
             continue;
@@ -581,19 +720,7 @@ __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
                 P.argmin[prob * P.n_out + i] = okk ? ui : nanv;
             }
         if (P.vmin) {
-            // the solve kernel's butterfly adds the p terms as ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7))
-            double t[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                t[q] = 0.0;
-                if (q < PD) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int c = 0; c < PD; ++c) s = fma(tab[L.Sxx + (size_t)q * PD + c], x[c], s);
-                    t[q] = x[q] * fma(0.5, s, tab[L.sx + q]);
-                }
-            }
-            const double vq = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            const double vq = vunc_terms<PD>(tab, L, x);
             P.vmin[prob] = okk ? (tab[L.s0] + vq) - 0.0 : nanv;
         }
         if (P.active)

@@ -67,4 +67,11 @@ __host__ __device__ inline WsLayout ws_layout(int n, int m, int p)
     return L;
 }
 
+// The prepared workspace of ONE shared mpQP (pympc_mpqp_prepare) carries, after the layout above, the Gram matrix of
+// the constant rows:  Gr [mp x mp],  Gr[i][j] = M_i . M_j  (row i contiguous over the columns).  With it the dual
+// vector of the NNLS follows from the passive coefficients alone,  w = -(1 + m'y) m(x) - sum_l y_l Gr[P_l]  (qp_wave.hpp),
+// one row per passive column instead of the n + 1 rows of the matrix.  Per-problem workspaces (pympc_qp_solve_batch,
+// pympc_mpqp_multi_solve) do not have it.
+__host__ __device__ inline size_t ws_gram_doubles(const WsLayout &L) { return (size_t)L.mp * L.mp; }
+
 }  // namespace pympc

@@ -53,7 +53,8 @@ void pympc_hip_limits(int *n_max, int *m_max);
  * pympc/control/controllers.py:76-124 (feedforward / feedback).
  * ------------------------------------------------------------------------------------------------- */
 
-/* Number of doubles of caller-owned device workspace `ws` that pympc_mpqp_prepare fills. */
+/* Number of doubles of caller-owned device workspace `ws` that pympc_mpqp_prepare fills (factorised constant part +
+ * the Gram matrix of its rows, mp x mp doubles with mp = m rounded up to the kernel's column padding: 1.2 MB for m = 370). */
 size_t pympc_mpqp_workspace_doubles(int n, int m, int p);
 
 /*

@@ -636,10 +636,13 @@ __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
             for (int q = 0; q < PD; ++q)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+            bool neg8 = false;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                neg = neg || (mv[u] < 0.0);
-                if (first_column) {
+            for (int u = 0; u < 8; ++u) neg8 = neg8 || (mv[u] < 0.0);
+            neg = neg || neg8;
+            if (first_column && __ballot(neg8) != 0ull) {   // (most groups of columns have no negative entry in any lane)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
                     const double wv = -mv[u];
                     const double d = fma(mv[u], mv[u], cn[j + u]);
                     const double sc = (wv > 0.0) ? wv * wv * __builtin_amdgcn_rcp(d) : -1.0;

@@ -126,6 +126,41 @@ def test_full_size_properties():
     assert np.abs(stat).max() < 1e-7 * max(1.0, np.abs(L).max())
 
 
+@pytest.mark.parametrize("scale,count", [(0.3, 40000), (0.6, 20000)])
+def test_screened_states_vs_per_problem_kernel(scale, count):
+    """The shared-matrix launch finishes most states in the screening pass (no active constraint; ONE active
+    constraint through the closed-form first column and a Gram row) and takes the first column of the others without a
+    factorisation.  The per-problem launch (pympc_qp_solve_batch: every QP factorised on its own, no screening, no Gram
+    matrix, Lawson-Hanson from the first column on) must give the same statuses and active sets and the same values to
+    rounding.  QP of state x: f = Hux x + fu, b = b - Ax x (parametric_programs.py:172-173)."""
+    from pympc_amd.optimization.solvers.hip import quadratic_program_batch
+    model = golden("c2_model")
+    x_max = model["x_max"]
+    X = np.random.RandomState(77).uniform(-scale * x_max, scale * x_max, (count, 4))
+    res = _prepared(model).solve_batch(X, want_iters=True)
+    f = X.dot(model["Hux"].T) + model["fu"][None, :]
+    b = model["b"][None, :] - X.dot(model["Ax"].T)
+    ref = quadratic_program_batch(model["Huu"], f, model["Au"], b)
+    st = res.numpy("status")
+    assert np.array_equal(st, ref.numpy("status"))
+    ok = st == 0
+    lam_r = ref.numpy("multiplier_inequality")[ok]
+    edge = (np.abs(lam_r - 1e-7) < 1e-9 * np.maximum(1.0, np.abs(lam_r).max(axis=1, keepdims=True))).any(axis=1)
+    assert np.array_equal(res.active_mask()[ok][~edge], ref.active_mask()[ok][~edge])
+    assert _rel(res.numpy("argmin")[ok], ref.numpy("argmin")[ok]) < 1e-9
+    lam = res.numpy("multiplier_inequality")[ok]
+    err = np.abs(lam - lam_r) / np.maximum(1.0, np.abs(lam_r).max(axis=1, keepdims=True))
+    print('multipliers: max relative difference %.2e' % err.max())
+    assert err.max() < 1e-7   # two different factorisations of the same active set (north_star bar: 1e-6)
+    # min of the mpQP = min of the QP + .5 x'Hxx x + fx'x + g (parametric_programs.py:177)
+    lift = 0.5 * np.einsum("bi,ij,bj->b", X, model["Hxx"], X) + X.dot(model["fx"]) + float(model["g"])
+    assert _rel(res.numpy("min")[ok], (ref.numpy("min") + lift)[ok]) < 1e-8
+    it = res.numpy("iters")
+    one = ok & (it[:, 0] == 1)
+    assert one.sum() > 0.15 * count          # the one-active-constraint states this test is about
+    assert (res.active_mask()[one].sum(axis=1) <= 1).all()
+
+
 @pytest.mark.parametrize("n,m,p", [(40, 800, 6), (63, 2048, 3), (5, 64, 2), (33, 129, 8)])
 def test_mpqp_shapes_beyond_the_lds_image(oracle, n, m, p):
     """mpQPs whose constant matrix cannot be staged in LDS beside four problems (and the limits n = 63, m = 2048) run

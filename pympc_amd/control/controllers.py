@@ -4,12 +4,13 @@
         feedforward(x) / feedback(x)                            :76-124    x 1-D: reference semantics (None when
                                                                            infeasible); x [B x nx]: one launch, arrays
         store_explicit_solution / feedforward_explicit / feedback_explicit   :126-186
-    HybridModelPredictiveController(S, N, Q, R, P, X_N)         :252-680   fixed-mode-sequence side only:
+    HybridModelPredictiveController(S, N, Q, R, P, X_N)         :252-680   fixed-mode-sequence side and big-M set-up:
         get_mpqp(mode_sequence)                                 :668-680
+        _get_bigM_dynamics() / _get_bigM_domains()              :289-405   one batched LP launch per domain
         get_mpqp_batch(mode_sequences) / solve_mode_sequences(x, mode_sequences)      (batched, new)
     condense_optimal_control_problem(S, Q, R, P, X_N, mode_sequence)                :682-749
 
-The mixed-integer feedback of the hybrid controller (big-M MIQP through Gurobi, :289-666) is outside the pnnls path.
+The mixed-integer program itself (mpMIQP condensing and its solution through Gurobi, :407-666) is outside the pnnls path.
 """
 import numpy as np
 import torch
@@ -133,6 +134,62 @@ class HybridModelPredictiveController(object):
 
     def get_mpqp(self, mode_sequence):
         return condense_optimal_control_problem(self.S, self.Q, self.R, self.P, self.X_N, mode_sequence, self.tables())
+
+    def _domain_lps(self, j, F):
+        """min f'z over the domain D_j for every row f of F [K x (nx + nu)]: ONE batched launch against the shared
+        (A, b) of D_j, equalities folded as rows (C, -C) like pnnls.py:101-106.  Returns the K optimal values (a
+        ValueError names the domain if one of them is unbounded or the domain is empty)."""
+        from ..optimization.solvers import hip_lp
+        D = self.S.domains[j]
+        A, b = D.A, D.b
+        if D.C.shape[0] > 0:
+            A = np.vstack((A, D.C, -D.C))
+            b = np.concatenate((b, D.d, -D.d))
+        res = hip_lp.linear_program_batch(np.ascontiguousarray(F), A, b, want_argmin=False, want_mult=False,
+                                          want_active=False)
+        st = res.numpy('status')
+        if np.any(st == 3):
+            raise RuntimeError('Maximum number of iterations reached.')
+        if np.any(st != 0):
+            raise ValueError('big-M LP over domain %d has no optimum (unbounded or empty domain).' % j)
+        return res.numpy('min')
+
+    def _get_bigM_dynamics(self):
+        """
+        Big-Ms of the PWA dynamics (controllers.py:289-358): alpha[i][j] = min over D_j of A_i x + B_i u + c_i,
+        beta[i][j] = max of the same, component by component (column vectors, as the reference returns them).  The
+        reference solves 2 nx LPs per pair (i, j) one after the other; here every LP over the same domain D_j, for all
+        i and both signs, is one batched launch.
+        """
+        S = self.S.affine_systems
+        s = len(S)
+        rows = np.vstack([np.hstack((Si.A, Si.B)) for Si in S])      # [sum nx x (nx + nu)], system i at rows off[i]:off[i+1]
+        off = np.cumsum([0] + [Si.nx for Si in S])
+        alpha = [[None] * s for _ in range(s)]
+        beta = [[None] * s for _ in range(s)]
+        for j in range(s):
+            v = self._domain_lps(j, np.vstack((rows, -rows)))
+            lo, hi = v[:rows.shape[0]], -v[rows.shape[0]:]
+            for i, Si in enumerate(S):
+                alpha[i][j] = (lo[off[i]:off[i + 1]] + Si.c).reshape(-1, 1)
+                beta[i][j] = (hi[off[i]:off[i + 1]] + Si.c).reshape(-1, 1)
+        return alpha, beta
+
+    def _get_bigM_domains(self):
+        """
+        Big-Ms of the PWA domains (controllers.py:360-405): gamma[i][j] = max over D_j of F_i x + G_i u - h_i, row by
+        row.  One batched launch per domain D_j for the rows of every D_i.
+        """
+        Ds = self.S.domains
+        s = len(Ds)
+        rows = np.vstack([D.A for D in Ds])
+        off = np.cumsum([0] + [D.A.shape[0] for D in Ds])
+        gamma = [[None] * s for _ in range(s)]
+        for j in range(s):
+            v = -self._domain_lps(j, -rows)
+            for i, D in enumerate(Ds):
+                gamma[i][j] = (v[off[i]:off[i + 1]] - D.b).reshape(-1, 1)
+        return gamma
 
     def get_mpqp_batch(self, mode_sequences):
         """Condenses every row of mode_sequences [B x N] in one launch -> MpqpBatch (device)."""

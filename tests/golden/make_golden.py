@@ -16,7 +16,7 @@ Records whose nnls call fails the certificate are kept and flagged
 ``oracle_invalid``; records whose thresholded active set sits on the 1e-7 edge
 are flagged ``degenerate``.
 
-Usage:  python tests/golden/make_golden.py [--only c1,c2,lp,nnls,nb,hybrid]
+Usage:  python tests/golden/make_golden.py [--only c1,c2,lp,nnls,nb,hybrid,bigm]
 """
 import os
 import sys
@@ -367,10 +367,51 @@ def gen_hybrid():
     np.savez_compressed(os.path.join(HERE, "hybrid_seqs.npz"), **out)
 
 
+def gen_bigm():
+    """Big-Ms of the hybrid controller's MIQP set-up (controllers.py:289-405) for the cart-pole PWA system: the
+    reference's own methods run on a bare object that only carries S (its __init__ goes on to build a Gurobi model).
+    Every value is certified against scipy.optimize.linprog (HiGHS), an independent LP solver."""
+    print("hybrid cart-pole big-Ms")
+    S_list, D_list, x_max = cart_pole_pieces()
+    S = PieceWiseAffineSystem(S_list, D_list)
+    holder = types.SimpleNamespace(S=S)
+    alpha, beta = HybridModelPredictiveController._get_bigM_dynamics(holder)
+    gamma = HybridModelPredictiveController._get_bigM_domains(holder)
+    s = len(S_list)
+
+    def lp_value(f, D):   # min f'z over D
+        r = scipy.optimize.linprog(f, A_ub=D.A, b_ub=D.b, bounds=(None, None), method="highs")
+        assert r.status == 0
+        return r.fun
+
+    worst = 0.0
+    for i in range(s):
+        Ai = np.hstack((S.affine_systems[i].A, S.affine_systems[i].B))
+        for j in range(s):
+            for k in range(Ai.shape[0]):
+                lo = lp_value(Ai[k], D_list[j]) + S.affine_systems[i].c[k]
+                hi = -lp_value(-Ai[k], D_list[j]) + S.affine_systems[i].c[k]
+                worst = max(worst, abs(lo - alpha[i][j][k, 0]), abs(hi - beta[i][j][k, 0]))
+            for k in range(D_list[i].A.shape[0]):
+                g = -lp_value(-D_list[i].A[k], D_list[j]) - D_list[i].b[k]
+                worst = max(worst, abs(g - gamma[i][j][k, 0]))
+    print("  max |reference - HiGHS| = %.2e" % worst)
+    assert worst < 1e-7
+    out = dict(S_A=np.array([t.A for t in S_list]), S_B=np.array([t.B for t in S_list]), S_c=np.array([t.c for t in S_list]),
+               certified_against_highs=np.asarray(worst))
+    for i, D in enumerate(D_list):
+        out["D%d_A" % i] = D.A; out["D%d_b" % i] = D.b
+    for i in range(s):
+        for j in range(s):
+            out["alpha_%d_%d" % (i, j)] = alpha[i][j]; out["beta_%d_%d" % (i, j)] = beta[i][j]
+            out["gamma_%d_%d" % (i, j)] = gamma[i][j]
+    np.savez_compressed(os.path.join(HERE, "hybrid_bigm.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="c1,c2,nb,lp,nnls,hybrid")
+    ap.add_argument("--only", default="c1,c2,nb,lp,nnls,hybrid,bigm")
     only = ap.parse_args().only.split(",")
-    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("hybrid", gen_hybrid)):
+    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("hybrid", gen_hybrid), ("bigm", gen_bigm)):
         if name in only:
             fn()

@@ -217,17 +217,19 @@ def main():
                        "plain_kernel_ms_without_cuts": plain_ms},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "qp_solve_kernel<%d,true> (+ mpqp_screen_kernel<%d> ahead of it, ~4 %% of the time)"
+                         "kernel": "qp_solve_kernel<%d,true> (+ mpqp_screen_kernel<%d> ahead of it, ~18 %% of the time)"
                                    % (2 * ((m + 127) // 128), p), "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": float(F.sum()), "executed_flops_per_launch": float(Fx.sum()),
                          "executed_tflops": Fx.sum() / (kern_ms * 1e-3) / 1e12,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_algorithmic_gbs": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_gbs": PEAK_HBM_GBS,
                          "note": "SURVEY 8(d): the NNLS kernel is bound by fp64 vector-ALU issue (+LDS), not by HBM or MFMA; "
-                                 "achieved = algorithmic active-set flops (SURVEY 8(d) formula on the kernel's own iteration counters: states "
-                                 "finished by the screening pass or by a certificate count their m(x) evaluation only) / HIP-event "
+                                 "achieved = algorithmic active-set flops (SURVEY 8(d) formula on the kernels' own iteration counters: states "
+                                 "without an active constraint or rejected by a certificate count their m(x) evaluation only) / HIP-event "
                                  "time of one step (certificate reset + screening kernel + solve kernel); "
-                                 "peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz"},
+                                 "peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (nominal; independent FMA chains sustain 53 "
+                                 "TFLOP/s on this part: benchmarks/fp64_rate.hip, profiles/r01_v4/fp64_rate.txt)",
+                         "measured_fp64_fma_tflops": 53.2},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(model, x_max, args.scale)

@@ -96,6 +96,7 @@ constexpr int kCutPMax = 8;
 constexpr int kCutHeader = 2;
 constexpr double kCutMargin = 1e-6;
 constexpr double kCutVerify = 1e-11;
+constexpr int kCutRecheckFrom = 6;   // passive columns from which a running solve looks at newly stored certificates
 __host__ __device__ inline size_t cut_table_doubles(int p) { return kCutHeader + (size_t)(p + 1) * kCutMax; }
 
 __device__ __forceinline__ double coherent_load(const double *a)
@@ -240,6 +241,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 #endif
     // ---- a stored certificate proves this state infeasible: no iterations
     const bool cut_hit = ncut > 0 && cut_fires(P.cuts, ncut, p, x0);
+    int ncut_seen = ncut;
 
     // ---- m(x) = m0 + Gm' x : the per-problem row of the NNLS matrix (pnnls.py:214)
     double mv[MT], w[MT];
@@ -474,6 +476,17 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
             }
         }
         PYMPC_TICK(5)
+        // A long solve is most often an infeasible state (the passive set is filling all n + 1 rows).  Other waves may
+        // have stored the certificate that rejects it since this one started: look again at the entries that are new.
+        if (P.cuts && status == kStatusOptimal && k >= kCutRecheckFrom && ((k - kCutRecheckFrom) & 3) == 0) {
+            const int now = cut_count(P.cuts);
+            if (now > ncut_seen) {
+                ncut_seen = now;
+                if (cut_fires(P.cuts, now, p, x0)) {
+                    status = kStatusInfeasible;
+                }
+            }
+        }
     }
 
     PYMPC_TICK(6)

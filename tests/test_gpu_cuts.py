@@ -41,8 +41,11 @@ def test_cuts_same_results_c2(scale, B):
     # a certificate never fires on a feasible state, and the warm table covers nearly every infeasible one
     assert not np.any(hit & (st == 0))
     assert hit.sum() >= 0.9 * (st == 1).sum()
-    # states that took the full solve report the plain kernel's counters
-    assert np.array_equal(it[~hit], plain.numpy("iters")[~hit])
+    # feasible states report the plain kernel's counters; an infeasible state may stop early when a certificate stored
+    # by another wave during its solve rejects it (never later than the plain solve)
+    pit = plain.numpy("iters")
+    assert np.array_equal(it[st == 0], pit[st == 0])
+    assert np.all(it[st == 1, 0] <= pit[st == 1, 0])
 
 
 def test_cuts_reset_and_golden_c1():

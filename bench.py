@@ -228,7 +228,7 @@ def main():
                                  "without an active constraint or rejected by a certificate count their m(x) evaluation only) / HIP-event "
                                  "time of one step (certificate reset + screening kernel + solve kernel); "
                                  "peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (nominal; independent FMA chains sustain 53 "
-                                 "TFLOP/s on this part: benchmarks/fp64_rate.hip, profiles/r01_v4/fp64_rate.txt)",
+                                 "TFLOP/s on this part: benchmarks/fp64_rate.hip, profiles/r01_v5/fp64_rate.txt)",
                          "measured_fp64_fma_tflops": 53.2},
         }
         if world == 1 and not args.no_cpu:

@@ -182,7 +182,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
 
 extern "C" {
 
-int pympc_hip_abi_version(void) { return 4; }
+int pympc_hip_abi_version(void) { return 5; }   // 5: the prepared mpQP workspace carries the Gram matrix
 
 const char *pympc_hip_last_error(void) { return g_err; }
 

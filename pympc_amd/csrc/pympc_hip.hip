@@ -92,11 +92,14 @@ int launch_solve(int mt, const SolveParams &P, int nwaves, size_t lds_bytes, lon
 // Launch geometry of the per-problem prepare workgroup: one thread per constraint row of a tile (up to 256 rows,
 // fewer when two row tiles of that size would not fit beside the factor matrices in ~96 KiB of LDS).
 struct PrepGeom { int threads, tile_rows; size_t lds_bytes; };
-PrepGeom prep_geom(int n, int m, int p)
+constexpr long long kPrepSmallBatch = 1024;
+PrepGeom prep_geom(int n, int m, int p, long long B = 1)
 {
     PrepGeom G;
     int tr = ((m + 63) / 64) * 64;
     if (tr > 256) tr = 256;
+    // many problems with small Hessians: one wavefront per problem (its barriers cost nothing, more workgroups per CU)
+    if (B >= kPrepSmallBatch && n * n < 1024) tr = 64;
     while (tr > 64 && prep_lds_doubles(n, p, tr) * 8 > 96 * 1024) tr -= 64;
     G.tile_rows = tr;
     G.threads = (n * n >= 1024 && tr < 256) ? 256 : tr;
@@ -293,7 +296,7 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
     Q.b = b; Q.b_stride = m;
     Q.g_host = 0.0;
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
-    const PrepGeom G = prep_geom(n, m, Q.p);
+    const PrepGeom G = prep_geom(n, m, Q.p, B);
     Q.tile_rows = G.tile_rows;
     if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
     hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);
@@ -339,7 +342,7 @@ int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, co
     Q.Ax = Ax; Q.ax_stride = (long long)m * p;
     Q.b = b; Q.b_stride = m;
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
-    const PrepGeom G = prep_geom(n, m, Q.p);
+    const PrepGeom G = prep_geom(n, m, Q.p, B);
     Q.tile_rows = G.tile_rows;
     if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
     hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);

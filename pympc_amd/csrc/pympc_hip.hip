@@ -144,12 +144,12 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     const size_t lds_bytes = shared_bytes + 16 + wave_bytes * nwaves;
     long long chunk = nwaves, nwg;
     if (shared) {
-        // one persistent workgroup per CU over interleaved slices (qp_solve_kernel); slices of 16 problems once the batch
-        // fills the chip (measured: 16 balances the waves better than 64 at 1M states), smaller ones below that so that every
-        // wave still has work
+        // one persistent workgroup per CU over interleaved slices (qp_solve_kernel); slices of 8 problems once the batch
+        // fills the chip (measured at 1M states with the screening pass ahead: 4 and 8 equal, 16 is 2 % and 32 is 5 % slower),
+        // smaller ones below that so that every wave still has work
         int ncu = cu_count();
         if (ncu <= 0) ncu = 256;
-        chunk = 16;
+        chunk = 8;
         while (chunk > 1 && P.B < chunk * nwaves * ncu) chunk >>= 1;
         const long long nslice = (P.B + chunk - 1) / chunk;
         const long long want = (nslice + nwaves - 1) / nwaves;   // workgroups that still give every wave a slice

@@ -182,3 +182,36 @@ def test_mpqp_shapes_beyond_the_lds_image(oracle, n, m, p):
     lam = ref["multiplier_inequality"][feas]
     edge = np.abs(lam - 1e-7) < 1e-9                       # multipliers sitting on the 1e-7 threshold
     assert np.array_equal(res.active_mask()[feas][~edge], ref["active"][feas][~edge])
+
+
+@pytest.mark.parametrize("n,m,p,scale", [(6, 40, 2, .6), (12, 150, 4, .5), (20, 300, 6, .4), (9, 90, 8, .5), (3, 20, 1, 1.5),
+                                         (30, 500, 3, .4)])
+def test_random_mpqps_shared_launch_vs_per_problem_kernel(n, m, p, scale):
+    """Random strictly convex mpQPs of several shapes (every parameter count the screening pass is compiled for is
+    close by): the shared-matrix launch (screening passes, closed-form first column, certificates) against the
+    per-problem kernel on the same QPs.  Statuses and active sets identical, values to 1e-7."""
+    from pympc_amd.optimization.solvers.hip import PreparedMpqp, quadratic_program_batch
+    rng = np.random.RandomState(1000 * n + m + p)
+    L = rng.randn(n, n); Huu = L.dot(L.T) + n * np.eye(n)
+    Hux = rng.randn(n, p); fu = rng.randn(n); fx = rng.randn(p)
+    Au = rng.randn(m, n); Ax = rng.randn(m, p); b = np.abs(rng.randn(m)) * 3. + 1.
+    X = rng.randn(4000, p) * scale
+    prep = PreparedMpqp(Huu, Hux, np.eye(p), fu, fx, .5, Au, Ax, b)
+    res = prep.solve_batch(X, want_iters=True)
+    again = prep.solve_batch(X, want_iters=True)      # certificate table from the first pass
+    ref = quadratic_program_batch(Huu, X.dot(Hux.T) + fu[None, :], Au, b[None, :] - X.dot(Ax.T))
+    st = ref.numpy("status")
+    assert set(np.unique(st)).issubset({0, 1}) and (st == 0).sum() > 100
+    for r in (res, again):
+        assert np.array_equal(r.numpy("status"), st)
+        ok = st == 0
+        lam_r = ref.numpy("multiplier_inequality")[ok]
+        scale_l = np.maximum(1.0, np.abs(lam_r).max(axis=1, keepdims=True))
+        edge = (np.abs(lam_r - 1e-7) < 1e-9 * scale_l).any(axis=1)
+        assert np.array_equal(r.active_mask()[ok][~edge], ref.active_mask()[ok][~edge])
+        assert _rel(r.numpy("argmin")[ok], ref.numpy("argmin")[ok]) < 1e-7
+        assert np.max(np.abs(r.numpy("multiplier_inequality")[ok] - lam_r) / scale_l) < 1e-7
+        lift = 0.5 * np.einsum("bi,bi->b", X, X) + X.dot(fx) + .5
+        assert _rel(r.numpy("min")[ok], (ref.numpy("min") + lift)[ok]) < 1e-7
+    it = res.numpy("iters")
+    print("n=%d m=%d p=%d: feasible %.2f, no column %.2f, one column %.2f" % (n, m, p, (st == 0).mean(), ((st == 0) & (it[:, 0] == 0)).mean(), ((st == 0) & (it[:, 0] == 1)).mean()))

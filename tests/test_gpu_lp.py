@@ -203,6 +203,15 @@ def test_shared_matrix_lockstep_kernel_vs_workgroup_kernel(n, m):
         assert np.allclose(big.numpy('min')[sl], ref.numpy('min'), rtol=1e-12, atol=1e-12)
         assert np.allclose(big.numpy('argmin')[sl], ref.numpy('argmin'), rtol=1e-9, atol=1e-9)
         assert np.allclose(big.numpy('multiplier_inequality')[sl], ref.numpy('multiplier_inequality'), rtol=1e-9, atol=1e-9)
+    # no relaxed row at all: generic objectives over the polytope
+    F = rng.randn(1500, n)
+    big = linear_program_batch(F, A, b, want_iters=True)
+    assert big.feasible.all()
+    for lo in range(0, 1500, 500):
+        ref = linear_program_batch(F[lo:lo + 500], A, b, want_iters=True)
+        assert np.array_equal(big.numpy('iters')[lo:lo + 500], ref.numpy('iters'))
+        assert np.array_equal(big.numpy('active_bits')[lo:lo + 500], ref.numpy('active_bits'))
+        assert np.allclose(big.numpy('argmin')[lo:lo + 500], ref.numpy('argmin'), rtol=1e-9, atol=1e-9)
     # an empty polyhedron: every LP ends with a Farkas certificate in phase 2 (status 1, NaN outputs)
     A2 = np.vstack((A, np.eye(n)[0], -np.eye(n)[0]))
     b2 = np.concatenate((b, [-5., -5.]))

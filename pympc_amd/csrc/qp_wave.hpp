@@ -607,6 +607,9 @@ __device__ __forceinline__ double vunc_terms(cdouble_ptr tab, const WsLayout &L,
 template <int PD>
 __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
 {
+    __shared__ double s_x[256 * PD];   // pass-2 candidates of the workgroup, packed
+    __shared__ int s_id[256], s_j[256];
+    __shared__ int s_cnt;
     const WsLayout &L = P.L;
     const int n = P.n, m = P.m, mp = L.mp, nw = (m + 31) / 32;
     const cdouble_ptr m0 = as_const(P.ws + L.m0), Gm = as_const(P.ws + L.Gm), tab = as_const(P.ws), cn = as_const(P.ws + L.cn);
@@ -616,9 +619,14 @@ __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
     const double nanv = __builtin_nan("");
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long nround = (P.B + stride - 1) / stride;   // wave-uniform trip count (the constant loads are scalar)
+    const int tid = threadIdx.x;
     for (long long r = 0; r < nround; ++r) {
-        const long long prob = r * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long base = r * stride + (long long)blockIdx.x * blockDim.x;
+        const long long prob = base + tid;
         const bool valid = prob < P.B;
+        __syncthreads();   // the previous round's candidate list is no longer read
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
         double x[PD];
 #pragma unroll
         for (int q = 0; q < PD; ++q) x[q] = valid ? P.X[prob * P.x_stride + q] : 0.0;
@@ -665,22 +673,70 @@ __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
             if (!first_column && __ballot(valid && !neg && !hit) == 0ull) break;   // nobody left to clear
         }
         const bool ws_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
-        // ---- states with ONE active constraint (most of the rest in an MPC batch): with the single passive column jb
-        // the NNLS solution is y = -m_j / (cn_j + m_j^2); it is optimal when the next dual vector
+        const bool cand = first_column && valid && ws_ok && neg && !hit && best > 0.0;
+        // ---- everything that is not a candidate for pass 2 is finished (or handed to the solve kernel) by its own thread
+        if (valid && !cand) {
+            if (!ws_ok || (neg && !hit)) {
+                P.status[prob] = kStatusPending;
+            } else {
+                const bool okk = !hit;
+                P.status[prob] = okk ? kStatusOptimal : kStatusInfeasible;
+                if (P.iters) { P.iters[2 * prob] = 0; P.iters[2 * prob + 1] = 0; }
+                if (P.argmin)
+                    for (int i = 0; i < P.n_out; ++i) {
+                        double ui = tab[L.u0 + i];
+#pragma unroll
+                        for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
+                        P.argmin[prob * P.n_out + i] = okk ? ui : nanv;
+                    }
+                if (P.vmin) {
+                    const double vq = vunc_terms<PD>(tab, L, x);
+                    P.vmin[prob] = okk ? (tab[L.s0] + vq) - 0.0 : nanv;
+                }
+                if (P.active)
+                    for (int e = 0; e < nw; ++e) P.active[prob * nw + e] = 0u;
+                if (P.mult)
+                    for (int j = 0; j < m; ++j) P.mult[prob * m + j] = okk ? 0.0 : nanv;
+            }
+        }
+        if (!first_column) continue;   // (the same in every thread: no barrier is skipped by part of the workgroup)
+        // ---- the candidates of the workgroup, packed: whole wavefronts work on pass 2 or skip it
+        {
+            const unsigned long long mask = __ballot(cand);
+            const int lane = tid & 63;
+            int sb = 0;
+            if (lane == 0 && mask != 0ull) sb = atomicAdd(&s_cnt, __popcll(mask));
+            sb = __builtin_amdgcn_readfirstlane(sb);
+            const int slot = sb + __popcll(mask & ((1ull << lane) - 1ull));
+            if (cand) {
+#pragma unroll
+                for (int q = 0; q < PD; ++q) s_x[slot * PD + q] = x[q];
+                s_id[slot] = tid;
+                s_j[slot] = jb;
+            }
+        }
+        __syncthreads();
+        const int n1 = s_cnt;
+        // ---- pass 2: states with ONE active constraint (most of the rest in an MPC batch): with the single passive
+        // column j the NNLS solution is y = -m_j / (cn_j + m_j^2); it is optimal when the next dual vector
         // w_i = -(1 + m_j y) m_i - y Gr[j][i] (qp_wave_solve, first column) has no positive entry.  Checked here per lane
         // with the same arithmetic; the state is then finished without ever reaching the wave kernel.
-        bool one = first_column && valid && ws_ok && neg && !hit && best > 0.0;
-        double y1 = 0.0, r2v = 1.0, mj = 0.0;
-        if (__ballot(one) != 0ull) {
-            const int jj = one ? jb : 0;
-            mj = m0[jj];   // (per-lane index: vector loads here)
+        if ((tid & ~63) < n1) {
+            const bool act = tid < n1;
+            const int t = act ? tid : 0;
+            double cx[PD];
 #pragma unroll
-            for (int q = 0; q < PD; ++q) mj = fma(Gm[(size_t)q * mp + jj], x[q], mj);
+            for (int q = 0; q < PD; ++q) cx[q] = s_x[t * PD + q];
+            const long long prob2 = base + s_id[t];
+            const int jj = s_j[t];
+            double mj = m0[jj];   // (per-lane index: vector loads here)
+#pragma unroll
+            for (int q = 0; q < PD; ++q) mj = fma(Gm[(size_t)q * mp + jj], cx[q], mj);
             const double cj = cn[jj];
             const double dj = fma(mj, mj, cj);
-            y1 = fast_div(-mj, dj);
-            r2v = fast_div(cj, dj);
-            one = one && (y1 < kGramMaxCoeff) && (fast_sqrt(r2v) > P.tol);
+            const double y1 = fast_div(-mj, dj);
+            const double r2v = fast_div(cj, dj);
+            bool one = act && (y1 < kGramMaxCoeff) && (fast_sqrt(r2v) > P.tol);
             const double ny = -y1, ng = -r2v;
             const double *grow = P.gram + jj;   // Gr is symmetric: column jj of row i
             for (int j = 0; j < mp && __ballot(one) != 0ull; j += 8) {
@@ -692,57 +748,34 @@ __global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
 #pragma unroll
                 for (int q = 0; q < PD; ++q)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+                    for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], cx[q], mv[u]);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const double wv = fma(ny, g[u], ng * mv[u]);
                     if (wv > 0.0 && j + u < m && j + u != jj) one = false;   // a second column would enter
                 }
             }
-        }
-        if (!valid) continue;
-        if (one) {
-            const double my = mj * y1;
-            const double ginv = fast_div(1.0, 1.0 + my);
-            const double lam = y1 * ginv;
-            P.status[prob] = kStatusOptimal;
-            if (P.iters) { P.iters[2 * prob] = 1; P.iters[2 * prob + 1] = 1; }
-            if (P.argmin)
-                for (int i = 0; i < P.n_out; ++i) {
-                    double ui = tab[L.u0 + i];
+            if (act && !one) P.status[prob2] = kStatusPending;
+            if (act && one) {
+                const double my = mj * y1;
+                const double ginv = fast_div(1.0, 1.0 + my);
+                const double lam = y1 * ginv;
+                P.status[prob2] = kStatusOptimal;
+                if (P.iters) { P.iters[2 * prob2] = 1; P.iters[2 * prob2 + 1] = 1; }
+                if (P.argmin)
+                    for (int i = 0; i < P.n_out; ++i) {
+                        double ui = tab[L.u0 + i];
 #pragma unroll
-                    for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
-                    P.argmin[prob * P.n_out + i] = fma(-lam, P.ws[L.T + (size_t)jb * n + i], ui);
-                }
-            if (P.vmin) P.vmin[prob] = (tab[L.s0] + vunc_terms<PD>(tab, L, x)) - 0.5 * my * ginv;
-            if (P.active)
-                for (int e = 0; e < nw; ++e) P.active[prob * nw + e] = (e == (jb >> 5) && lam > P.tol) ? (1u << (jb & 31)) : 0u;
-            if (P.mult)
-                for (int j = 0; j < m; ++j) P.mult[prob * m + j] = (j == jb) ? lam : 0.0;
-            continue;
-        }
-        if (!ws_ok || (neg && !hit)) {
-            P.status[prob] = kStatusPending;
-            continue;
-        }
-        const bool okk = !hit;
-        P.status[prob] = okk ? kStatusOptimal : kStatusInfeasible;
-        if (P.iters) { P.iters[2 * prob] = 0; P.iters[2 * prob + 1] = 0; }
-        if (P.argmin)
-            for (int i = 0; i < P.n_out; ++i) {
-                double ui = tab[L.u0 + i];
-#pragma unroll
-                for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
-                P.argmin[prob * P.n_out + i] = okk ? ui : nanv;
+                        for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], cx[q], ui);
+                        P.argmin[prob2 * P.n_out + i] = fma(-lam, P.ws[L.T + (size_t)jj * n + i], ui);
+                    }
+                if (P.vmin) P.vmin[prob2] = (tab[L.s0] + vunc_terms<PD>(tab, L, cx)) - 0.5 * my * ginv;
+                if (P.active)
+                    for (int e = 0; e < nw; ++e) P.active[prob2 * nw + e] = (e == (jj >> 5) && lam > P.tol) ? (1u << (jj & 31)) : 0u;
+                if (P.mult)
+                    for (int j = 0; j < m; ++j) P.mult[prob2 * m + j] = (j == jj) ? lam : 0.0;
             }
-        if (P.vmin) {
-            const double vq = vunc_terms<PD>(tab, L, x);
-            P.vmin[prob] = okk ? (tab[L.s0] + vq) - 0.0 : nanv;
         }
-        if (P.active)
-            for (int e = 0; e < nw; ++e) P.active[prob * nw + e] = 0u;
-        if (P.mult)
-            for (int j = 0; j < m; ++j) P.mult[prob * m + j] = okk ? 0.0 : nanv;
     }
 }
 

@@ -89,8 +89,10 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
  * relative margin of 1e-6 without iterating (status PYMPC_INFEASIBLE, iters (0, 0)); states nearer to the boundary
  * take the full solve, so the feasibility decision is the reference's.  `cuts`: pympc_mpqp_cuts_doubles(p) doubles
  * of device memory owned by the caller, zeroed by pympc_mpqp_cuts_reset before first use and whenever `ws` is
- * prepared again; it belongs to ONE prepared mpQP, is read and appended to by the kernel (launches on different
- * streams may share it) and can be kept across calls.  NULL, p = 0 or p > 8: no certificates (plain solve).
+ * prepared again; it belongs to ONE prepared mpQP, is read and appended to by the kernel and can be kept across calls.
+ * Launches that share a table must be ordered on ONE stream (the screening kernel reads the entries that were complete
+ * when it started through the scalar cache; a concurrent launch appending to the same table is not supported).
+ * NULL, p = 0 or p > 8: no certificates (plain solve).
  */
 size_t pympc_mpqp_cuts_doubles(int p);
 int pympc_mpqp_cuts_reset(int p, double *cuts, void *stream);

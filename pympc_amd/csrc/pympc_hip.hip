@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/pympc_hip.h"
 #include "condense.hpp"
@@ -53,13 +54,33 @@ int check_launch(const char *what)
     return 0;
 }
 
+// Kernels that take more than 64 KiB of dynamic LDS need the attribute once per (kernel, device); the largest size
+// granted so far is remembered so that steady-state launches make no runtime call for it.
+constexpr int kMaxDevices = 64;
+struct LdsGrant { const void *fn; int dev; size_t bytes; };
 template <typename K>
 int allow_lds(K kernel, size_t bytes)
 {
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    if (bytes <= 64 * 1024) return 0;
+    static std::mutex mu;
+    static LdsGrant grants[128];
+    static int ngrants = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    LdsGrant *slot = nullptr;
+    if (dev >= 0) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (int i = 0; i < ngrants; ++i)
+            if (grants[i].fn == fn && grants[i].dev == dev) { slot = &grants[i]; break; }
+        if (slot && slot->bytes >= bytes) return 0;
+    }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    if (dev >= 0) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!slot && ngrants < 128) { slot = &grants[ngrants++]; slot->fn = fn; slot->dev = dev; slot->bytes = 0; }
+        if (slot && slot->bytes < bytes) slot->bytes = bytes;
     }
     return 0;
 }

@@ -105,7 +105,8 @@ __device__ __forceinline__ double coherent_load(const double *a)
 }
 __device__ __forceinline__ int cut_count(const double *cuts)
 {
-    const int c = __hip_atomic_load(reinterpret_cast<const int *>(cuts), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // acquire: pairs with the writer's release store of `count`, so the entries it covers are visible to the loads below
+    const int c = __hip_atomic_load(reinterpret_cast<const int *>(cuts), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     return __builtin_amdgcn_readfirstlane(min(c, kCutMax));
 }
 

@@ -100,6 +100,21 @@ int pympc_mpqp_solve_batch_cuts(int n, int m, int p, const double *ws, double *c
                                 int n_out, double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
                                 int32_t *iters, void *stream);
 
+/*
+ * pympc_mpqp_solve_batch_cuts for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The certificate table
+ * lives in a file-scope device array of the library (18 448 bytes per GPU, held until the process ends; its device
+ * address is looked up once per GPU with hipGetSymbolAddress on the first call there) instead of caller memory, and
+ * is emptied at the start of EVERY call (hipMemsetAsync on `stream`), because the certificates of the last call belong
+ * to that call's mpQP.  Needs 1 <= p <= 8 (the certificates' limit): anything else returns PYMPC_ERR_UNSUPPORTED.
+ * Calls neither hipMalloc nor hipFree.  All calls on one GPU share that GPU's table: calls that overlap in time on one
+ * GPU (different streams or threads) race on it and must be serialised by the caller.  Outputs as
+ * pympc_mpqp_solve_batch_cuts with an empty table (statuses and solutions identical to the plain solve).
+ */
+int pympc_mpqp_solve_batch_static(int n, int m, int p, const double *ws, const double *X, int64_t B, double tol, int n_out,
+                                  double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
+                                  int32_t *iters, void *stream);
+
 /* -------------------------------------------------------------------------------------------------
  * Per-problem batched QP: B independent problems  min .5 x'H_k x + f_k'x  s.t. A_k x <= b_k  of equal
  * shape (n, m); equalities are folded by the caller as rows (C, -C) exactly as pnnls.py:202-207 does.

@@ -202,6 +202,33 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
                   : launch_solve<false>(mt, P, nwaves, lds_bytes, nwg, st);
 }
 
+// ---- device scratch of the entry point that allocates nothing (pympc_mpqp_solve_batch_static): the table of learned
+// infeasibility certificates, sized for the largest parameter count the certificates support.  Every GPU the library
+// runs on holds its own copy until the process ends.  In host code the array's NAME is only a handle for
+// hipGetSymbolAddress: the device address is looked up once per device and kept in g_scratch[dev].
+constexpr size_t kScratchDoubles = kCutHeader + (size_t)(kCutPMax + 1) * kCutMax;   // 2 306 doubles = 18 448 B
+static __device__ __align__(256) double scratch[kScratchDoubles];
+double *g_scratch[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+int scratch_address(double **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PYMPC_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch[dev]) {
+        void *addr = nullptr;
+        e = hipGetSymbolAddress(&addr, HIP_SYMBOL(scratch));   // with device `dev` current: that GPU's copy
+        if (e != hipSuccess || !addr)
+            return fail(PYMPC_ERR_LAUNCH, "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch[dev] = static_cast<double *>(addr);
+    }
+    *out = g_scratch[dev];
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -288,6 +315,22 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
 {
     return pympc_mpqp_solve_batch_cuts(n, m, p, ws, nullptr, X, B, tol, n_out, argmin, vmin, mult, active, status, iters,
                                        stream);
+}
+
+int pympc_mpqp_solve_batch_static(int n, int m, int p, const double *ws, const double *X, int64_t B, double tol, int n_out,
+                                  double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
+                                  int32_t *iters, void *stream)
+{
+    if (p < 1 || p > kCutPMax)
+        return fail(PYMPC_ERR_UNSUPPORTED,
+                    "pympc_mpqp_solve_batch_static: the static certificate table holds 1 <= p <= %d parameters, got %d "
+                    "(%zu bytes of device scratch per GPU)", kCutPMax, p, kScratchDoubles * sizeof(double));
+    double *table = nullptr;
+    if (int rc = scratch_address(&table)) return rc;
+    // the table keeps the last call's certificates, which belong to that call's mpQP: start from an empty one
+    hipError_t e = hipMemsetAsync(table, 0, cut_table_doubles(p) * sizeof(double), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipMemsetAsync(static scratch): %s", hipGetErrorString(e));
+    return pympc_mpqp_solve_batch_cuts(n, m, p, ws, table, X, B, tol, n_out, argmin, vmin, mult, active, status, iters, stream);
 }
 
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)

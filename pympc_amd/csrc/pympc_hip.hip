@@ -14,6 +14,7 @@
 #include "point_location.hpp"
 #include "qp_prepare.hpp"
 #include "qp_wave.hpp"
+#include "qp_screen.hpp"
 #include "ws_layout.hpp"
 
 using namespace pympc;
@@ -136,8 +137,18 @@ int check_shape(int n, int m, int p)
     return 0;
 }
 
+// Learning pre-pass of a large shared-matrix batch with a certificate table: kLearnStates states, taken at a constant
+// stride over the batch, are solved first with ONE wavefront per SIMD (a full infeasible solve is a serial chain of
+// ~24 pivots: alone on its SIMD it runs three times faster than beside two others), so that the table holds the
+// certificates of the batch's infeasible regions before the main launch starts.  Without it every wave of the main
+// launch meets its first infeasible state with an empty table and solves it in full at the same time as all others.
+// The pre-pass writes no outputs: its statuses go to the head of the caller's status array, which the main launch
+// overwrites.  With a table that is already warm it finds nothing to learn and costs two nearly empty launches.
+constexpr long long kLearnMinBatch = 131072;
+constexpr long long kLearnStates = 8192;
+
 // Common launch geometry of the solve kernel.
-int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t st)
+int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t st, bool learn_pass = false)
 {
     const int R = n + 1;
     P.n = n; P.m = m; P.p = p;
@@ -146,6 +157,14 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     P.wave_doubles = wave_lds_doubles(n, p, P.RP);
     const int mt = P.L.mp / 64;
     const size_t wave_bytes = (size_t)P.wave_doubles * 8;
+    if (shared && !learn_pass && P.cuts && p >= 1 && p <= kCutPMax && P.x_stride == p && P.B >= kLearnMinBatch) {
+        SolveParams A = P;
+        const long long step = P.B / kLearnStates;
+        A.B = kLearnStates;
+        A.x_stride = (long long)p * step;
+        A.argmin = nullptr; A.vmin = nullptr; A.mult = nullptr; A.active = nullptr; A.iters = nullptr;
+        if (int rc = solve_common(true, n, m, p, A, st, true)) return rc;
+    }
     // a matrix too large to be staged beside four problems stays in global memory (one workspace, ws_stride 0, read
     // through L2 by every wave) instead of being refused
     if (shared && shared_lds(n, P.L).total * 8 + 16 + 4 * wave_bytes > kLdsBytes) shared = false;
@@ -159,6 +178,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     const int max_waves = mt <= 8 ? 12 : 4;   // = solve_max_waves<MT>() (launch bounds of the kernel)
     const int cap = shared ? max_waves : 4;
     if (nwaves > cap) nwaves = cap;
+    if (learn_pass && nwaves > 4) nwaves = 4;   // one wavefront per SIMD
     if (shared && nwaves > 4) nwaves &= ~3;   // a multiple of the 4 SIMDs
     if ((long long)nwaves > P.B) nwaves = (int)P.B;
     if (nwaves < 1) nwaves = 1;
@@ -170,7 +190,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         // smaller ones below that so that every wave still has work
         int ncu = cu_count();
         if (ncu <= 0) ncu = 256;
-        chunk = 8;
+        chunk = learn_pass ? 2 : 8;
         while (chunk > 1 && P.B < chunk * nwaves * ncu) chunk >>= 1;
         const long long nslice = (P.B + chunk - 1) / chunk;
         const long long want = (nslice + nwaves - 1) / nwaves;   // workgroups that still give every wave a slice
@@ -180,12 +200,15 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         P.chunk = (int)chunk;
         // screening pass: states with a feasible unconstrained minimiser (and those a stored certificate rejects) finish here
         P.screened = 0;
-        if (p >= 1 && p <= 8 && P.x_stride == p) {
+        if (p >= 1 && p <= 8 && P.x_stride >= p && P.B <= 0x7fffffffLL) {
             P.screened = 1;
-            const int threads = 256;
-            long long sg = (P.B + threads - 1) / threads;
-            if (sg > 8LL * ncu) sg = 8LL * ncu;
-#define PYMPC_SCREEN_CASE(PD) case PD: hipLaunchKernelGGL(mpqp_screen_kernel<PD>, dim3((unsigned)sg), dim3(threads), 0, st, P); break;
+            // persistent workgroups, two per CU, each walking over whole tiles of states (qp_screen.hpp); the grid is
+            // evened out so that every workgroup gets the same number of tiles (+- 1)
+            const long long tile = (long long)kScreenThreads * (p <= 4 ? 2 : 1);   // = kScreenThreads * screen_states_per_lane<p>()
+            const long long ntile = (P.B + tile - 1) / tile;
+            const long long rounds = (ntile + 2LL * ncu - 1) / (2LL * ncu);
+            const long long sg = (ntile + rounds - 1) / rounds;
+#define PYMPC_SCREEN_CASE(PD) case PD: hipLaunchKernelGGL(mpqp_screen_kernel<PD>, dim3((unsigned)sg), dim3(kScreenThreads), 0, st, P); break;
             switch (p) {
                 PYMPC_SCREEN_CASE(1) PYMPC_SCREEN_CASE(2) PYMPC_SCREEN_CASE(3) PYMPC_SCREEN_CASE(4)
                 PYMPC_SCREEN_CASE(5) PYMPC_SCREEN_CASE(6) PYMPC_SCREEN_CASE(7) PYMPC_SCREEN_CASE(8)

@@ -1,0 +1,663 @@
+// Screening kernel of the shared-matrix batch (MultiParametricQuadraticProgram.solve over a batch of states,
+// /root/reference/pympc/optimization/parametric_programs.py:155-179 -> pympc/optimization/solvers/pnnls.py:149-241):
+// one state per LANE, ahead of the wave-per-problem kernel (qp_wave.hpp).  Most states of an MPC batch end with none,
+// one or two active constraints; for those the NNLS of pnnls.py:216-230 is a handful of scalar formulas plus sweeps
+// over the columns, which a lane does for its own state with every lane of the wavefront busy.
+//
+//   stage 0  (every state)   m(x) = m0 + Gm'x.  No negative entry: the NNLS stops before its first column (y = 0),
+//            the state is finished with the unconstrained minimiser.  A stored infeasibility certificate fires: finished
+//            as infeasible.  Otherwise the column the NNLS takes first (largest w^2 / |a|^2 over w = -m(x) > 0, lowest
+//            index among equals: the rule of qp_wave_solve) goes into queue 1 with the state's index.
+//   stage K  (K = 1 .. kScreenStages, entries of queue K: state + passive columns c_1 .. c_K)
+//            NNLS solution on the passive set from the Gram matrix of the constant rows:  with G = Gr[P][P] = M_P M_P',
+//            z = G^-1 m_P,  t = m_P'z:   y = -z / (1 + t),   residual^2 = gamma = 1 / (1 + t)   (Sherman-Morrison on
+//            G + m_P m_P'; every term of t is positive: no cancellation).  Next dual vector
+//            w_j = -gamma m_j - sum_l y_l Gr[c_l][j]:  no positive entry => optimal, the state is finished here
+//            (lambda = -z, V = V_unc + t / 2, u = u_unc - sum_l lambda_l T[c_l]);  otherwise the best next column
+//            joins the passive set in queue K + 1.  A state leaves the lane path for the wave kernel (status
+//            kStatusPending, solved there from scratch) when a coefficient is not positive (Lawson-Hanson would drop a
+//            column), a pivot of G is small (nearly dependent rows), a coefficient is large or the residual is small
+//            (near-infeasible), or after the last stage.
+//
+// MI355X mapping.  The constants of a sweep (m0, Gm, cn: the same for every lane) come through the scalar cache and
+// enter the FMAs as scalar operands; that path delivers only a few bytes per clock per CU, so stage 0 keeps S states
+// per lane (each loaded constant feeds S FMAs).  The Gram entries of a lane's own passive columns are gathered
+// (Gr is symmetric: lanes read column c_l of the row the sweep is at, so a wavefront's loads fall into one 3 KB row).
+// Candidates are packed: a persistent workgroup pushes them into LDS queues while it walks over its tiles of states
+// and runs a stage only on full wavefronts' worth of entries (the remainders are flushed once at the end), so that
+// every lane of every stage pass works.  Outputs of a finished state are written by its lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qp_wave.hpp"
+
+namespace pympc {
+
+constexpr int kScreenThreads = 512;
+constexpr int kScreenStages = 2;          // lane-path stages after stage 0: states with up to this many active constraints
+constexpr double kScreenPivotMin = 1e-6;  // relative pivot of G below which the rows count as nearly dependent
+constexpr double kScreenGammaMin = 1e-8;  // squared residual below which the state counts as near-infeasible
+template <int PD>
+constexpr int screen_states_per_lane() { return PD <= 4 ? 2 : 1; }
+
+// x'(.5 Sxx x + sx) with the p terms added as the solve kernel's butterfly adds them:
+// ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7))
+template <int PD>
+__device__ __forceinline__ double vunc_terms(cdouble_ptr tab, const WsLayout &L, const double (&x)[PD])
+{
+    double t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        t[q] = 0.0;
+        if (q < PD) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < PD; ++c) s = fma(tab[L.Sxx + (size_t)q * PD + c], x[c], s);
+            t[q] = x[q] * fma(0.5, s, tab[L.sx + q]);
+        }
+    }
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
+// Outputs of a state finished on the lane path.  K = 0: no active constraint (okk: optimal, else infeasible by a
+// certificate).  K >= 1: passive columns cols[] with multipliers lam[] (all positive), tq = t of the header.
+template <int PD, int K>
+__device__ __forceinline__ void screen_write(const SolveParams &P, cdouble_ptr tab, long long prob, const double (&x)[PD],
+                                             bool okk, const int *cols, const double *lam, double tq)
+{
+    const WsLayout &L = P.L;
+    const int n = P.n, m = P.m, nw = (m + 31) / 32;
+    const double nanv = __builtin_nan("");
+    P.status[prob] = okk ? kStatusOptimal : kStatusInfeasible;
+    if (P.iters) { P.iters[2 * prob] = K; P.iters[2 * prob + 1] = K; }
+    if (P.argmin)
+        for (int i = 0; i < P.n_out; ++i) {
+            double ui = tab[L.u0 + i];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
+#pragma unroll
+            for (int l = 0; l < K; ++l) ui = fma(-lam[l], P.ws[L.T + (size_t)cols[l] * n + i], ui);
+            P.argmin[prob * P.n_out + i] = okk ? ui : nanv;
+        }
+    if (P.vmin) {
+        const double vq = vunc_terms<PD>(tab, L, x);
+        P.vmin[prob] = okk ? (tab[L.s0] + vq) + 0.5 * tq : nanv;
+    }
+    if (P.active)
+        for (int e = 0; e < nw; ++e) {
+            uint32_t word = 0u;
+#pragma unroll
+            for (int l = 0; l < K; ++l)
+                if (e == (cols[l] >> 5) && lam[l] > P.tol) word |= 1u << (cols[l] & 31);
+            P.active[prob * nw + e] = word;
+        }
+    if (P.mult)
+        for (int j = 0; j < m; ++j) {
+            double v = okk ? 0.0 : nanv;
+#pragma unroll
+            for (int l = 0; l < K; ++l)
+                if (j == cols[l]) v = lam[l];
+            P.mult[prob * m + j] = v;
+        }
+}
+
+enum { kScreenDone = 0, kScreenNext = 1, kScreenPunt = 2 };
+
+// Stage K for the state of this lane (act: the lane holds an entry).  Returns kScreenDone (outputs written),
+// kScreenNext (jnext = column to add) or kScreenPunt (status set to pending).  Full wavefront: the sweep is wave-uniform.
+template <int PD, int K>
+__device__ __forceinline__ int screen_stage(const SolveParams &P, cdouble_ptr m0, cdouble_ptr Gm, cdouble_ptr cn, cdouble_ptr tab,
+                                            bool act, long long prob, const int (&cols)[K], int &jnext)
+{
+    const WsLayout &L = P.L;
+    const int m = P.m, mp = L.mp;
+    double x[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) x[q] = act ? P.X[prob * P.x_stride + q] : 0.0;
+    // ---- passive rows: m_P(x), G = Gr[P][P] (diagonal = cn), its LDL' factorisation, z = G^-1 m_P
+    double mP[K], D[K], Lm[K][K], v[K], z[K], y[K], lam[K];
+    bool ok = act;
+#pragma unroll
+    for (int l = 0; l < K; ++l) {
+        const int c = act ? cols[l] : 0;
+        double s = P.ws[L.m0 + c];   // (per-lane index: vector loads)
+#pragma unroll
+        for (int q = 0; q < PD; ++q) s = fma(P.ws[L.Gm + (size_t)q * mp + c], x[q], s);
+        mP[l] = s;
+    }
+    double tq = 0.0, gamma = 1.0;
+    if constexpr (K == 1) {
+        // the closed form of qp_wave_solve's first column
+        const double cj = P.ws[L.cn + (act ? cols[0] : 0)];
+        const double dj = fma(mP[0], mP[0], cj);
+        y[0] = fast_div(-mP[0], dj);
+        gamma = fast_div(cj, dj);
+        ok = ok && (y[0] < kGramMaxCoeff) && (fast_sqrt(gamma) > P.tol);
+        const double my = mP[0] * y[0];
+        lam[0] = y[0] * fast_div(1.0, 1.0 + my);
+        tq = -my * fast_div(1.0, 1.0 + my);   // V - V_unc = -.5 m'y / (1 + m'y)
+    } else {
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const int ca = act ? cols[a] : 0;
+            const double gaa = P.ws[L.cn + ca];
+            double d = gaa;
+#pragma unroll
+            for (int b = 0; b < a; ++b) {
+                double g = P.gram[(size_t)ca * mp + (act ? cols[b] : 0)];
+#pragma unroll
+                for (int c = 0; c < b; ++c) g = fma(-Lm[a][c] * D[c], Lm[b][c], g);
+                Lm[a][b] = fast_div(g, D[b]);
+                d = fma(-Lm[a][b] * D[b], Lm[a][b], d);
+            }
+            D[a] = d;
+            ok = ok && (d > kScreenPivotMin * gaa);
+            if (!(d > 0.0)) D[a] = 1.0;   // (keeps the arithmetic of a punted lane finite)
+        }
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            double s = mP[a];
+#pragma unroll
+            for (int b = 0; b < a; ++b) s = fma(-Lm[a][b], v[b], s);
+            v[a] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            z[a] = fast_div(v[a], D[a]);
+            tq = fma(v[a], z[a], tq);
+        }
+#pragma unroll
+        for (int a = K - 1; a >= 0; --a) {
+            double s = z[a];
+#pragma unroll
+            for (int b = a + 1; b < K; ++b) s = fma(-Lm[b][a], z[b], s);
+            z[a] = s;
+        }
+        gamma = fast_div(1.0, 1.0 + tq);
+        ok = ok && (gamma > kScreenGammaMin);
+#pragma unroll
+        for (int l = 0; l < K; ++l) {
+            lam[l] = -z[l];
+            y[l] = lam[l] * gamma;
+            ok = ok && (lam[l] > 0.0) && (y[l] < kGramMaxCoeff);
+        }
+    }
+    // ---- next dual vector over all columns; the best entering column along the way
+    bool more = false;
+    double best = -1.0;
+    int jb = 0;
+    const double ng = -gamma;
+    const double *grow[K];
+#pragma unroll
+    for (int l = 0; l < K; ++l) grow[l] = P.gram + (act ? cols[l] : 0);   // Gr is symmetric: column c_l of row j
+    for (int j = 0; j < mp && __ballot(ok) != 0ull; j += 8) {
+        double mv[8], g[K][8];
+#pragma unroll
+        for (int l = 0; l < K; ++l)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[l][u] = grow[l][(size_t)(j + u) * mp];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = m0[j + u];
+#pragma unroll
+        for (int q = 0; q < PD; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+        double wv[8];
+        bool pos8 = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            double w = ng * mv[u];
+#pragma unroll
+            for (int l = 0; l < K; ++l) w = fma(-y[l], g[l][u], w);
+            bool self = j + u >= m;
+#pragma unroll
+            for (int l = 0; l < K; ++l) self = self || (j + u == cols[l]);
+            wv[u] = self ? -1.0 : w;
+            pos8 = pos8 || (wv[u] > 0.0);
+        }
+        more = more || pos8;
+        if (K < kScreenStages && __ballot(ok && pos8) != 0ull) {   // (a last stage only needs to know whether a column enters)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double d = fma(mv[u], mv[u], cn[j + u]);
+                const double sc = (wv[u] > 0.0) ? wv[u] * wv[u] * __builtin_amdgcn_rcp(d) : -1.0;
+                if (sc > best) { best = sc; jb = j + u; }
+            }
+        }
+        if (K >= kScreenStages && __ballot(ok && !more) == 0ull) break;   // nobody left who could still be optimal
+    }
+    if (!act) return kScreenDone;
+    if (ok && !more) {
+        screen_write<PD, K>(P, tab, prob, x, true, cols, lam, tq);
+        return kScreenDone;
+    }
+    if (ok && K < kScreenStages && best > 0.0) {
+        jnext = jb;
+        return kScreenNext;
+    }
+    P.status[prob] = kStatusPending;
+    return kScreenPunt;
+}
+
+// ------------------------------------------------------------------------------------------------ generic stage
+// Passive sets of 3 .. kScreenKMax columns, one Lawson-Hanson step per pass: the entry's last column is the one that
+// just entered.  Coefficients y on the passive set from the Gram matrix (LDL' of G = Gr[P][P], as above).  If one of
+// them is not positive the step is Lawson-Hanson's secondary loop: interpolate from the previous coefficients (those of
+// the set without the new column, recomputed from the leading block of the same factorisation) to the first zero,
+// drop the columns that reached it, solve again on what is left (one such round per pass; a second one, a new column
+// whose own coefficient is not positive, or a small pivot send the state to the wave kernel).  Then the dual sweep:
+// optimal -> outputs; otherwise the set grows by the best column and goes back into the queue.
+constexpr int kScreenKMax = 6;
+
+template <int KM>
+struct LaneSolve {
+    double lam[KM];   // multipliers -(G^-1 m_P)
+    double tq;        // m_P'G^-1 m_P
+    bool ok;          // pivots fine
+};
+
+// LDL' solve on the first K (<= KM) entries of cols (per lane).  mP: m(x) on those columns.
+template <int KM>
+__device__ __forceinline__ LaneSolve<KM> lane_gram_solve(const SolveParams &P, const int (&cols)[KM], int K, const double (&mP)[KM],
+                                                         LaneSolve<KM> *lead /* solution on the first K - 1 columns, or null */)
+{
+    const WsLayout &L = P.L;
+    const int mp = L.mp;
+    double D[KM], Lm[KM][KM], v[KM], z[KM];
+    LaneSolve<KM> S;
+    S.ok = true;
+#pragma unroll
+    for (int a = 0; a < KM; ++a) {
+        const bool ina = a < K;
+        const int ca = ina ? cols[a] : 0;
+        const double gaa = P.ws[L.cn + ca];
+        double d = gaa;
+#pragma unroll
+        for (int b = 0; b < a; ++b) {
+            double g = P.gram[(size_t)ca * mp + ((b < K) ? cols[b] : 0)];
+#pragma unroll
+            for (int c = 0; c < b; ++c) g = fma(-Lm[a][c] * D[c], Lm[b][c], g);
+            Lm[a][b] = ina ? fast_div(g, D[b]) : 0.0;
+            d = fma(-Lm[a][b] * D[b], Lm[a][b], d);
+        }
+        S.ok = S.ok && (!ina || d > kScreenPivotMin * gaa);
+        D[a] = (ina && d > 0.0) ? d : 1.0;
+    }
+#pragma unroll
+    for (int a = 0; a < KM; ++a) {
+        double s = (a < K) ? mP[a] : 0.0;
+#pragma unroll
+        for (int b = 0; b < a; ++b) s = fma(-Lm[a][b], v[b], s);
+        v[a] = s;
+    }
+    // the same forward substitution serves the leading (K - 1) block: only the back substitution differs
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !lead) break;
+        const int Kp = pass == 0 ? K : K - 1;
+        double tq = 0.0;
+#pragma unroll
+        for (int a = 0; a < KM; ++a) {
+            z[a] = (a < Kp) ? fast_div(v[a], D[a]) : 0.0;
+            tq = fma((a < Kp) ? v[a] : 0.0, z[a], tq);
+        }
+#pragma unroll
+        for (int a = KM - 1; a >= 0; --a) {
+            double s = z[a];
+#pragma unroll
+            for (int b = a + 1; b < KM; ++b) s = fma(-Lm[b][a], (b < Kp) ? z[b] : 0.0, s);
+            z[a] = (a < Kp) ? s : 0.0;
+        }
+        LaneSolve<KM> &T = pass == 0 ? S : *lead;
+        T.tq = tq;
+#pragma unroll
+        for (int a = 0; a < KM; ++a) T.lam[a] = -z[a];
+    }
+    return S;
+}
+
+template <int PD, int KM>
+__device__ __forceinline__ void screen_write_k(const SolveParams &P, cdouble_ptr tab, long long prob, const double (&x)[PD],
+                                               int K, const int (&cols)[KM], const double (&lam)[KM], double tq, int outer, int inner)
+{
+    const WsLayout &L = P.L;
+    const int n = P.n, m = P.m, nw = (m + 31) / 32;
+    P.status[prob] = kStatusOptimal;
+    if (P.iters) { P.iters[2 * prob] = outer; P.iters[2 * prob + 1] = inner; }
+    if (P.argmin)
+        for (int i = 0; i < P.n_out; ++i) {
+            double ui = tab[L.u0 + i];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
+#pragma unroll
+            for (int l = 0; l < KM; ++l)
+                if (l < K) ui = fma(-lam[l], P.ws[L.T + (size_t)cols[l] * n + i], ui);
+            P.argmin[prob * P.n_out + i] = ui;
+        }
+    if (P.vmin) P.vmin[prob] = (tab[L.s0] + vunc_terms<PD>(tab, L, x)) + 0.5 * tq;
+    if (P.active)
+        for (int e = 0; e < nw; ++e) {
+            uint32_t word = 0u;
+#pragma unroll
+            for (int l = 0; l < KM; ++l)
+                if (l < K && e == (cols[l] >> 5) && lam[l] > P.tol) word |= 1u << (cols[l] & 31);
+            P.active[prob * nw + e] = word;
+        }
+    if (P.mult)
+        for (int j = 0; j < m; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < KM; ++l)
+                if (l < K && j == cols[l]) v = lam[l];
+            P.mult[prob * m + j] = v;
+        }
+}
+
+// One generic pass for the state of this lane.  In: K columns (the last one new), outer / inner iteration counters so
+// far.  Returns kScreenDone / kScreenNext (cols, K updated with the next column appended) / kScreenPunt.
+template <int PD, int KM>
+__device__ __forceinline__ int screen_stage_k(const SolveParams &P, cdouble_ptr m0, cdouble_ptr Gm, cdouble_ptr cn, cdouble_ptr tab,
+                                              bool act, long long prob, int (&cols)[KM], int &K, int &outer, int &inner)
+{
+    const WsLayout &L = P.L;
+    const int m = P.m, mp = L.mp;
+    double x[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) x[q] = act ? P.X[prob * P.x_stride + q] : 0.0;
+    if (!act) K = 0;
+    double mP[KM];
+#pragma unroll
+    for (int l = 0; l < KM; ++l) {
+        if (l >= K) cols[l] = 0;
+        double s = P.ws[L.m0 + cols[l]];
+#pragma unroll
+        for (int q = 0; q < PD; ++q) s = fma(P.ws[L.Gm + (size_t)q * mp + cols[l]], x[q], s);
+        mP[l] = s;
+    }
+    bool ok = act;
+    LaneSolve<KM> lead;
+    LaneSolve<KM> S = lane_gram_solve<KM>(P, cols, K, mP, &lead);
+    ok = ok && S.ok;
+    ++inner;
+    bool drop = false;
+#pragma unroll
+    for (int l = 0; l < KM; ++l) drop = drop || (l < K && !(S.lam[l] > 0.0));
+    if (ok && drop) {
+        // Lawson-Hanson secondary loop, one round: y_old on the set without the new column (0 for the new one),
+        // alpha = min over the non-positive coefficients of y_old / (y_old - y)
+        const double g_new = fast_div(1.0, 1.0 + S.tq), g_old = fast_div(1.0, 1.0 + lead.tq);
+        double yo[KM], yn[KM];
+        double alpha = 2.0;
+        bool lead_ok = true;
+#pragma unroll
+        for (int l = 0; l < KM; ++l) {
+            yo[l] = (l < K - 1) ? lead.lam[l] * g_old : 0.0;
+            yn[l] = (l < K) ? S.lam[l] * g_new : 0.0;
+            lead_ok = lead_ok && !(l < K - 1 && !(yo[l] > 0.0));
+            if (l < K && !(yn[l] > 0.0)) alpha = fmin(alpha, fast_div(yo[l], yo[l] - yn[l]));
+        }
+        // the new column's own coefficient is not positive (alpha = 0), or the previous set was not a solution: not ours
+        ok = ok && lead_ok && (alpha > 0.0) && (alpha <= 1.0);
+        int Kn = 0;
+        int cn2[KM];
+        double mn2[KM];
+#pragma unroll
+        for (int l = 0; l < KM; ++l) { cn2[l] = 0; mn2[l] = 0.0; }
+#pragma unroll
+        for (int l = 0; l < KM; ++l) {
+            const double yi = fma(alpha, yn[l] - yo[l], yo[l]);
+            const bool keep = l < K && yi > 0.0 && (yn[l] > 0.0 || fast_div(yo[l], yo[l] - yn[l]) > alpha);
+            if (keep) {
+#pragma unroll
+                for (int t = 0; t < KM; ++t)
+                    if (t == Kn) { cn2[t] = cols[l]; mn2[t] = mP[l]; }
+                ++Kn;
+            }
+        }
+        ok = ok && Kn >= 1 && Kn < K;
+#pragma unroll
+        for (int l = 0; l < KM; ++l) { cols[l] = cn2[l]; mP[l] = mn2[l]; }
+        K = ok ? Kn : 0;
+        S = lane_gram_solve<KM>(P, cols, K, mP, nullptr);
+        ++inner;
+        ok = ok && S.ok;
+#pragma unroll
+        for (int l = 0; l < KM; ++l) ok = ok && !(l < K && !(S.lam[l] > 0.0));   // a second round: the wave kernel's
+    }
+    const double gamma = fast_div(1.0, 1.0 + S.tq);
+    ok = ok && (gamma > kScreenGammaMin);
+    double y[KM];
+#pragma unroll
+    for (int l = 0; l < KM; ++l) {
+        y[l] = (l < K) ? S.lam[l] * gamma : 0.0;
+        ok = ok && (y[l] < kGramMaxCoeff);
+    }
+    // ---- dual sweep
+    bool more = false;
+    double best = -1.0;
+    int jb = 0;
+    const double ng = -gamma;
+    for (int j = 0; j < mp && __ballot(ok) != 0ull; j += 4) {
+        double mv[4], g[KM][4];
+#pragma unroll
+        for (int l = 0; l < KM; ++l)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[l][u] = P.gram[(size_t)(j + u) * mp + cols[l]];   // Gr symmetric: column c_l of row j
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mv[u] = m0[j + u];
+#pragma unroll
+        for (int q = 0; q < PD; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+        unsigned self = 0u;
+#pragma unroll
+        for (int l = 0; l < KM; ++l)
+            if (l < K && (cols[l] >> 2) == (j >> 2)) self |= 1u << (cols[l] & 3);
+        double wv[4];
+        bool pos4 = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double w = ng * mv[u];
+#pragma unroll
+            for (int l = 0; l < KM; ++l) w = fma(-y[l], g[l][u], w);
+            wv[u] = (((self >> u) & 1u) || j + u >= m) ? -1.0 : w;
+            pos4 = pos4 || (wv[u] > 0.0);
+        }
+        more = more || pos4;
+        if (__ballot(ok && pos4) != 0ull) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double d = fma(mv[u], mv[u], cn[j + u]);
+                const double sc = (wv[u] > 0.0) ? wv[u] * wv[u] * __builtin_amdgcn_rcp(d) : -1.0;
+                if (sc > best) { best = sc; jb = j + u; }
+            }
+        }
+    }
+    if (!act) return kScreenDone;
+    if (ok && !more) {
+        screen_write_k<PD, KM>(P, tab, prob, x, K, cols, S.lam, S.tq, outer, inner);
+        return kScreenDone;
+    }
+    if (ok && K < KM && best > 0.0) {
+#pragma unroll
+        for (int t = 0; t < KM; ++t)
+            if (t == K) cols[t] = jb;
+        ++K;
+        ++outer;
+        return kScreenNext;
+    }
+    P.status[prob] = kStatusPending;
+    return kScreenPunt;
+}
+
+// append (id, cols[0..K]) of the lanes with `push` to a queue in LDS (whole workgroup; no barrier inside)
+template <int KC>
+__device__ __forceinline__ void screen_push(bool push, int *cnt, int *qid, int (*qcol)[KC], int cap_unused, int id,
+                                            const int *cols)
+{
+    (void)cap_unused;
+    const unsigned long long mask = __ballot(push);
+    const int lane = threadIdx.x & 63;
+    int sb = 0;
+    if (lane == 0 && mask != 0ull) sb = atomicAdd(cnt, __popcll(mask));
+    sb = __builtin_amdgcn_readfirstlane(sb);
+    const int slot = sb + __popcll(mask & ((1ull << lane) - 1ull));
+    if (push) {
+        qid[slot] = id;
+#pragma unroll
+        for (int l = 0; l < KC; ++l) qcol[slot][l] = cols[l];
+    }
+}
+
+template <int PD>
+__global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams P)
+{
+    constexpr int S = screen_states_per_lane<PD>();
+    constexpr int NT = kScreenThreads;
+    constexpr int TILE = NT * S;
+    static_assert(kScreenStages == 2, "queues below are written for two lane-path stages");
+    __shared__ int q1_id[TILE + NT], q1_col[TILE + NT][1];
+    __shared__ int q2_id[2 * NT], q2_col[2 * NT][2];
+    __shared__ int q_cnt[2];
+    const WsLayout &L = P.L;
+    const int mp = L.mp;
+    const cdouble_ptr m0 = as_const(P.ws + L.m0), Gm = as_const(P.ws + L.Gm), tab = as_const(P.ws), cn = as_const(P.ws + L.cn);
+    const int ncut = P.cuts ? cut_count(P.cuts) : 0;
+    const cdouble_ptr cut = as_const(P.cuts);   // entries [0, ncut) were complete before this launch started
+    const int tid = threadIdx.x;
+    const bool ws_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
+    if (tid < 2) q_cnt[tid] = 0;
+    __syncthreads();
+
+    // run stage 1 / stage 2 on the top `take` entries of their queues
+    auto pass1 = [&](int take) {
+        const int cnt = q_cnt[0];
+        __syncthreads();
+        const bool act = tid < take;
+        const int e = act ? cnt - take + tid : 0;
+        if ((tid & ~63) < take) {
+            const int id = q1_id[e];
+            int cols[1] = {q1_col[e][0]};
+            int jn = 0;
+            const int r = screen_stage<PD, 1>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
+            int c2[2] = {cols[0], jn};
+            screen_push<2>(act && r == kScreenNext, &q_cnt[1], q2_id, q2_col, 0, id, c2);
+        }
+        __syncthreads();
+        if (tid == 0) q_cnt[0] = cnt - take;
+        __syncthreads();
+    };
+    auto pass2 = [&](int take) {
+        const int cnt = q_cnt[1];
+        __syncthreads();
+        const bool act = tid < take;
+        const int e = act ? cnt - take + tid : 0;
+        if ((tid & ~63) < take) {
+            const int id = q2_id[e];
+            int cols[2] = {q2_col[e][0], q2_col[e][1]};
+            int jn = 0;
+            (void)screen_stage<PD, 2>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
+        }
+        __syncthreads();
+        if (tid == 0) q_cnt[1] = cnt - take;
+        __syncthreads();
+    };
+
+    const long long ntile = (P.B + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        double x[S][PD];
+        bool valid[S], hit[S], neg[S];
+        double best[S];
+        int jb[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const long long prob = base + (long long)s * NT + tid;
+            valid[s] = prob < P.B;
+#pragma unroll
+            for (int q = 0; q < PD; ++q) x[s][q] = valid[s] ? P.X[prob * P.x_stride + q] : 0.0;
+            hit[s] = false;
+            neg[s] = false;
+            best[s] = -1.0;
+            jb[s] = 0;
+        }
+        // ---- stored certificates (same test as cut_fires)
+        for (int c = 0; c < ncut; ++c) {
+            const double cc = cut[kCutHeader + c];
+            double dq[PD];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) dq[q] = cut[kCutHeader + (size_t)(q + 1) * kCutMax + c];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                double v = cc, a = fabs(cc);
+#pragma unroll
+                for (int q = 0; q < PD; ++q) {
+                    const double t = dq[q] * x[s][q];
+                    v += t;
+                    a += fabs(t);
+                }
+                hit[s] = hit[s] || (v < -kCutMargin * a);
+            }
+        }
+        // ---- m(x): is some entry negative?  (a NaN state has none: the solve kernel also finds no column for it)
+        // Along the way the column the NNLS would take first.
+        for (int j = 0; j < mp; j += 8) {
+            double c0[8], cg[PD][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c0[u] = m0[j + u];
+#pragma unroll
+            for (int q = 0; q < PD; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cg[q][u] = Gm[(size_t)q * mp + j + u];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                double mv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mv[u] = c0[u];
+#pragma unroll
+                for (int q = 0; q < PD; ++q)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) mv[u] = fma(cg[q][u], x[s][q], mv[u]);
+                bool neg8 = false;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) neg8 = neg8 || (mv[u] < 0.0);
+                neg[s] = neg[s] || neg8;
+                if (__ballot(neg8) != 0ull) {   // (most groups of columns have no negative entry in any lane)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double wv = -mv[u];
+                        const double d = fma(mv[u], mv[u], cn[j + u]);
+                        const double sc = (wv > 0.0) ? wv * wv * __builtin_amdgcn_rcp(d) : -1.0;
+                        if (sc > best[s]) { best[s] = sc; jb[s] = j + u; }
+                    }
+                }
+            }
+        }
+        // ---- finished here, handed to the wave kernel, or into queue 1
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const long long prob = base + (long long)s * NT + tid;
+            const bool cand = valid[s] && ws_ok && neg[s] && !hit[s] && best[s] > 0.0;
+            if (valid[s] && !cand) {
+                if (!ws_ok || (neg[s] && !hit[s])) P.status[prob] = kStatusPending;
+                else screen_write<PD, 0>(P, tab, prob, x[s], !hit[s], nullptr, nullptr, 0.0);
+            }
+            int c1[1] = {jb[s]};
+            screen_push<1>(cand, &q_cnt[0], q1_id, q1_col, 0, (int)prob, c1);
+        }
+        __syncthreads();
+        while (q_cnt[0] >= NT) {   // (workgroup-uniform: the counters only change between barriers)
+            pass1(NT);
+            if (q_cnt[1] >= NT) pass2(NT);
+        }
+    }
+    // ---- remainders
+    while (q_cnt[0] > 0) {
+        pass1(min(q_cnt[0], NT));
+        if (q_cnt[1] >= NT) pass2(NT);
+    }
+    while (q_cnt[1] > 0) pass2(min(q_cnt[1], NT));
+}
+
+}  // namespace pympc

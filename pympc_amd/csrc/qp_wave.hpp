@@ -578,208 +578,6 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     wave_sync_lds();
 }
 
-// ------------------------------------------------------------------------------------------------ screening pass
-// One state per LANE, before the wave-per-problem kernel: a state whose unconstrained minimiser is feasible
-// (m(x) = m0 + Gm'x >= 0: the first dual sweep of the NNLS finds no column, pnnls.py:216-230 returns y = 0) is
-// finished here for ~30 instructions instead of a wavefront's set-up, sweep and output stage; a state that a stored
-// infeasibility certificate rejects likewise.  The constants are wave-uniform: they come through the scalar cache
-// (8 columns of m0 / Gm per s_load) and enter the FMAs as scalar operands.  Every other state gets kStatusPending and
-// is solved by qp_solve_kernel.  The arithmetic (order of the FMAs of m(x), u_unc, V_unc) is the solve kernel's, so
-// a state gets the same bits from either path.
-// x'(.5 Sxx x + sx) with the p terms added as the solve kernel's butterfly adds them:
-// ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7))
-template <int PD>
-__device__ __forceinline__ double vunc_terms(cdouble_ptr tab, const WsLayout &L, const double (&x)[PD])
-{
-    double t[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        t[q] = 0.0;
-        if (q < PD) {
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < PD; ++c) s = fma(tab[L.Sxx + (size_t)q * PD + c], x[c], s);
-            t[q] = x[q] * fma(0.5, s, tab[L.sx + q]);
-        }
-    }
-    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-}
-
-template <int PD>
-__global__ void __launch_bounds__(256) mpqp_screen_kernel(SolveParams P)
-{
-    __shared__ double s_x[256 * PD];   // pass-2 candidates of the workgroup, packed
-    __shared__ int s_id[256], s_j[256];
-    __shared__ int s_cnt;
-    const WsLayout &L = P.L;
-    const int n = P.n, m = P.m, mp = L.mp, nw = (m + 31) / 32;
-    const cdouble_ptr m0 = as_const(P.ws + L.m0), Gm = as_const(P.ws + L.Gm), tab = as_const(P.ws), cn = as_const(P.ws + L.cn);
-    const bool first_column = P.gram != nullptr;   // wave-uniform
-    const int ncut = P.cuts ? cut_count(P.cuts) : 0;
-    const cdouble_ptr cut = as_const(P.cuts);   // entries [0, ncut) were complete before this launch started
-    const double nanv = __builtin_nan("");
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long nround = (P.B + stride - 1) / stride;   // wave-uniform trip count (the constant loads are scalar)
-    const int tid = threadIdx.x;
-    for (long long r = 0; r < nround; ++r) {
-        const long long base = r * stride + (long long)blockIdx.x * blockDim.x;
-        const long long prob = base + tid;
-        const bool valid = prob < P.B;
-        __syncthreads();   // the previous round's candidate list is no longer read
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        double x[PD];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) x[q] = valid ? P.X[prob * P.x_stride + q] : 0.0;
-        // ---- stored certificates (same test as cut_fires)
-        bool hit = false;
-        for (int c = 0; c < ncut; ++c) {
-            const double cc = cut[kCutHeader + c];
-            double v = cc, a = fabs(cc);
-#pragma unroll
-            for (int q = 0; q < PD; ++q) {
-                const double t = cut[kCutHeader + (size_t)(q + 1) * kCutMax + c] * x[q];
-                v += t;
-                a += fabs(t);
-            }
-            hit = hit || (v < -kCutMargin * a);
-        }
-        // ---- is some entry of m(x) negative?  (a NaN state has none: the solve kernel also finds no column for it)
-        // Along the way: the column the NNLS would take first (largest w^2 / |a|^2 over w = -m(x) > 0, lowest index among
-        // equals: the rule and the arithmetic of qp_wave_solve).
-        bool neg = false;
-        double best = -1.0;
-        int jb = 0;
-        for (int j = 0; j < mp; j += 8) {
-            double mv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mv[u] = m0[j + u];
-#pragma unroll
-            for (int q = 0; q < PD; ++q)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
-            bool neg8 = false;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) neg8 = neg8 || (mv[u] < 0.0);
-            neg = neg || neg8;
-            if (first_column && __ballot(neg8) != 0ull) {   // (most groups of columns have no negative entry in any lane)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double wv = -mv[u];
-                    const double d = fma(mv[u], mv[u], cn[j + u]);
-                    const double sc = (wv > 0.0) ? wv * wv * __builtin_amdgcn_rcp(d) : -1.0;
-                    if (sc > best) { best = sc; jb = j + u; }
-                }
-            }
-            if (!first_column && __ballot(valid && !neg && !hit) == 0ull) break;   // nobody left to clear
-        }
-        const bool ws_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
-        const bool cand = first_column && valid && ws_ok && neg && !hit && best > 0.0;
-        // ---- everything that is not a candidate for pass 2 is finished (or handed to the solve kernel) by its own thread
-        if (valid && !cand) {
-            if (!ws_ok || (neg && !hit)) {
-                P.status[prob] = kStatusPending;
-            } else {
-                const bool okk = !hit;
-                P.status[prob] = okk ? kStatusOptimal : kStatusInfeasible;
-                if (P.iters) { P.iters[2 * prob] = 0; P.iters[2 * prob + 1] = 0; }
-                if (P.argmin)
-                    for (int i = 0; i < P.n_out; ++i) {
-                        double ui = tab[L.u0 + i];
-#pragma unroll
-                        for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
-                        P.argmin[prob * P.n_out + i] = okk ? ui : nanv;
-                    }
-                if (P.vmin) {
-                    const double vq = vunc_terms<PD>(tab, L, x);
-                    P.vmin[prob] = okk ? (tab[L.s0] + vq) - 0.0 : nanv;
-                }
-                if (P.active)
-                    for (int e = 0; e < nw; ++e) P.active[prob * nw + e] = 0u;
-                if (P.mult)
-                    for (int j = 0; j < m; ++j) P.mult[prob * m + j] = okk ? 0.0 : nanv;
-            }
-        }
-        if (!first_column) continue;   // (the same in every thread: no barrier is skipped by part of the workgroup)
-        // ---- the candidates of the workgroup, packed: whole wavefronts work on pass 2 or skip it
-        {
-            const unsigned long long mask = __ballot(cand);
-            const int lane = tid & 63;
-            int sb = 0;
-            if (lane == 0 && mask != 0ull) sb = atomicAdd(&s_cnt, __popcll(mask));
-            sb = __builtin_amdgcn_readfirstlane(sb);
-            const int slot = sb + __popcll(mask & ((1ull << lane) - 1ull));
-            if (cand) {
-#pragma unroll
-                for (int q = 0; q < PD; ++q) s_x[slot * PD + q] = x[q];
-                s_id[slot] = tid;
-                s_j[slot] = jb;
-            }
-        }
-        __syncthreads();
-        const int n1 = s_cnt;
-        // ---- pass 2: states with ONE active constraint (most of the rest in an MPC batch): with the single passive
-        // column j the NNLS solution is y = -m_j / (cn_j + m_j^2); it is optimal when the next dual vector
-        // w_i = -(1 + m_j y) m_i - y Gr[j][i] (qp_wave_solve, first column) has no positive entry.  Checked here per lane
-        // with the same arithmetic; the state is then finished without ever reaching the wave kernel.
-        if ((tid & ~63) < n1) {
-            const bool act = tid < n1;
-            const int t = act ? tid : 0;
-            double cx[PD];
-#pragma unroll
-            for (int q = 0; q < PD; ++q) cx[q] = s_x[t * PD + q];
-            const long long prob2 = base + s_id[t];
-            const int jj = s_j[t];
-            double mj = m0[jj];   // (per-lane index: vector loads here)
-#pragma unroll
-            for (int q = 0; q < PD; ++q) mj = fma(Gm[(size_t)q * mp + jj], cx[q], mj);
-            const double cj = cn[jj];
-            const double dj = fma(mj, mj, cj);
-            const double y1 = fast_div(-mj, dj);
-            const double r2v = fast_div(cj, dj);
-            bool one = act && (y1 < kGramMaxCoeff) && (fast_sqrt(r2v) > P.tol);
-            const double ny = -y1, ng = -r2v;
-            const double *grow = P.gram + jj;   // Gr is symmetric: column jj of row i
-            for (int j = 0; j < mp && __ballot(one) != 0ull; j += 8) {
-                double mv[8], g[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) g[u] = grow[(size_t)(j + u) * mp];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) mv[u] = m0[j + u];
-#pragma unroll
-                for (int q = 0; q < PD; ++q)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], cx[q], mv[u]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double wv = fma(ny, g[u], ng * mv[u]);
-                    if (wv > 0.0 && j + u < m && j + u != jj) one = false;   // a second column would enter
-                }
-            }
-            if (act && !one) P.status[prob2] = kStatusPending;
-            if (act && one) {
-                const double my = mj * y1;
-                const double ginv = fast_div(1.0, 1.0 + my);
-                const double lam = y1 * ginv;
-                P.status[prob2] = kStatusOptimal;
-                if (P.iters) { P.iters[2 * prob2] = 1; P.iters[2 * prob2 + 1] = 1; }
-                if (P.argmin)
-                    for (int i = 0; i < P.n_out; ++i) {
-                        double ui = tab[L.u0 + i];
-#pragma unroll
-                        for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], cx[q], ui);
-                        P.argmin[prob2 * P.n_out + i] = fma(-lam, P.ws[L.T + (size_t)jj * n + i], ui);
-                    }
-                if (P.vmin) P.vmin[prob2] = (tab[L.s0] + vunc_terms<PD>(tab, L, cx)) - 0.5 * my * ginv;
-                if (P.active)
-                    for (int e = 0; e < nw; ++e) P.active[prob2 * nw + e] = (e == (jj >> 5) && lam > P.tol) ? (1u << (jj & 31)) : 0u;
-                if (P.mult)
-                    for (int j = 0; j < m; ++j) P.mult[prob2 * m + j] = (j == jj) ? lam : 0.0;
-            }
-        }
-    }
-}
-
 // LDS image of the constant part for the shared-matrix launch: Mt rows pitched by mp + 2 doubles (the column gather
 // Mt[lane][j] of the candidate test then spreads over 16 bank groups instead of one), and the small objective tables
 // ws[L.u0 .. L.total) (u0, Ku, Sxx, sx, s0, zeros).  m0 and Gm are read once per problem (m(x) = m0 + Gm'x), from

@@ -16,7 +16,7 @@ Records whose nnls call fails the certificate are kept and flagged
 ``oracle_invalid``; records whose thresholded active set sits on the 1e-7 edge
 are flagged ``degenerate``.
 
-Usage:  python tests/golden/make_golden.py [--only c1,c2,lp,nnls,nb,hybrid,bigm]
+Usage:  python tests/golden/make_golden.py [--only c1,c2,c2big,ctrl,lp,nnls,nb,hybrid,bigm]
 """
 import os
 import sys
@@ -222,6 +222,87 @@ def gen_c2():
         np.savez_compressed(os.path.join(HERE, "c2_solves_%s.npz" % tag), **rec)
 
 
+def gen_c2big():
+    """10 000 reference-run C2 states per distribution (the first 10 000 of the benchmark's own stream).
+    Kept compact: u0 .. u2, min, status, active-set bits, certificate flags (no multiplier rows)."""
+    print("C2 cart-pole N=20, 10 000 states per distribution")
+    ctrl, extra = build_c2()
+    x_max = extra['x_max']
+    for tag, s in (("s03", 0.3), ("s10", 1.0)):
+        X = np.random.RandomState(0).uniform(-s * x_max, s * x_max, (1000000, 4))[:10000]
+        rec = solve_batch(ctrl, X)
+        lam = rec.pop('multiplier_inequality')
+        rec['argmin'] = rec['argmin'][:, :3].copy()
+        rec['multiplier_sum'] = lam.sum(axis=1)
+        rec['multiplier_max'] = lam.max(axis=1)
+        np.savez_compressed(os.path.join(HERE, "c2_big_%s.npz" % tag), **rec)
+
+
+def gen_ctrl():
+    """Randomised linear MPC problems in the manner of the reference's controller tests (random stable-ish systems with
+    box constraints, LQR terminal cost, mcais terminal set): every quantity the reference computes is stored as data --
+    systems, horizons, the reference's P, K and terminal set, the sampled states, and for each state the reference's
+    feedforward (u, V), whether the state lies in the terminal set and the nnls certificate.  Explicit solutions: the
+    reference's store_explicit_solution is attempted per system (it fails under the container's scipy for some systems,
+    SURVEY 8c); where it works the explicit (u, V) are stored next to the implicit ones."""
+    print("randomised MPC controllers (implicit + explicit)")
+    rng = np.random.RandomState(1)
+    out = {}
+    count = 0
+    for kind, nsys in (("imp", 30), ("exp", 6)):
+        for i in range(nsys):
+            if kind == "imp":
+                n = rng.randint(2, 5); m = rng.randint(1, n); scale = 10.; N = rng.randint(5, 10)
+            else:
+                n = 2; m = 1; scale = 1.; N = 10
+            while True:
+                A = rng.rand(n, n) / scale; B = rng.rand(n, m) / scale
+                S = LinearSystem(A, B)
+                if S.controllable:
+                    break
+            x_min = -rng.rand(n); x_max = rng.rand(n); u_min = -rng.rand(m); u_max = rng.rand(m)
+            D = Polyhedron.from_bounds(x_min, x_max).cartesian_product(Polyhedron.from_bounds(u_min, u_max))
+            Q = np.eye(n); R = np.eye(m)
+            P, K = S.solve_dare(Q, R)
+            X_N = S.mcais(K, D)
+            ctrl = ModelPredictiveController(S, N, Q, R, P, D, X_N)
+            xs = rng.rand(10, n) * (x_max - x_min) + x_min
+            U = np.full((10, N * m), np.nan); V = np.full(10, np.nan); ok = np.zeros(10, bool); inside = np.zeros(10, bool)
+            Ue = np.full((10, N * m), np.nan); Ve = np.full(10, np.nan); have_e = np.zeros(10, bool)
+            explicit_ok = False
+            if kind == "exp":
+                try:
+                    ctrl.store_explicit_solution()
+                    explicit_ok = True
+                except Exception as e:   # scipy-1.15.3 nnls failure inside explicit_solve
+                    print("    system %d: store_explicit_solution failed (%s)" % (i, type(e).__name__))
+            for j, x in enumerate(xs):
+                (u, v), cert = certified_call(ctrl.feedforward, x)
+                ok[j] = cert
+                inside[j] = X_N.contains(x)
+                if v is not None:
+                    U[j] = np.concatenate(u); V[j] = v
+                if explicit_ok:
+                    try:
+                        ue, ve = ctrl.feedforward_explicit(x)
+                        have_e[j] = True
+                        if ve is not None:
+                            Ue[j] = np.concatenate(ue); Ve[j] = ve
+                    except Exception:
+                        pass
+            pre = "%s%d_" % (kind, i)
+            out.update({pre + "A": A, pre + "B": B, pre + "x_min": x_min, pre + "x_max": x_max, pre + "u_min": u_min,
+                        pre + "u_max": u_max, pre + "N": np.asarray(N), pre + "P": P, pre + "K": K,
+                        pre + "XN_A": X_N.A, pre + "XN_b": X_N.b, pre + "X": xs, pre + "U": U, pre + "V": V,
+                        pre + "oracle_valid": ok, pre + "inside": inside})
+            if kind == "exp":
+                out.update({pre + "Ue": Ue, pre + "Ve": Ve, pre + "have_explicit": have_e})
+            count += 1
+        out["n_" + kind] = np.asarray(nsys)
+    print("  %d systems" % count)
+    np.savez_compressed(os.path.join(HERE, "controllers.npz"), **out)
+
+
 def gen_nb():
     """examples/linear_mpc.ipynb: inverted pendulum N=6; anchors V*(x0) of cell 25."""
     print("linear_mpc.ipynb inverted pendulum N=6")
@@ -410,8 +491,8 @@ def gen_bigm():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="c1,c2,nb,lp,nnls,hybrid,bigm")
+    ap.add_argument("--only", default="c1,c2,c2big,ctrl,nb,lp,nnls,hybrid,bigm")
     only = ap.parse_args().only.split(",")
-    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("hybrid", gen_hybrid), ("bigm", gen_bigm)):
+    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("c2big", gen_c2big), ("ctrl", gen_ctrl), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("hybrid", gen_hybrid), ("bigm", gen_bigm)):
         if name in only:
             fn()

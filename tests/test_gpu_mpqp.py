@@ -69,6 +69,51 @@ def test_mpqp_batch_vs_reference_golden(model_name, solve_name):
         assert np.abs(model["Huu"].dot(u) + f + model["Au"].T.dot(lam)).max() < 1e-7 * max(1.0, np.abs(lam).max())
 
 
+@pytest.mark.parametrize("tag,min_feasible", [("s03", 8000), ("s10", 1500)])
+def test_mpqp_10k_reference_states(tag, min_feasible):
+    """the first 10 000 states of the benchmark's own stream (s = 0.3 and s = 1.0), every one solved by the
+    REFERENCE in the build container (tests/golden/make_golden.py::gen_c2big; compact records: u0..u2, min, active
+    bits, sum and max of the multipliers).  Feasibility decisions and active sets bit-exact, values to 1e-6; the few
+    records that are uncertified (scipy 1.15.3) or sit on the 1e-7 multiplier edge are counted and must
+    be few."""
+    model = golden("c2_model")
+    rec = golden("c2_big_" + tag)
+    m = model["Au"].shape[0]
+    res = _prepared(model).solve_batch(rec["X"], want_iters=True)
+    st = res.numpy("status")
+    assert set(np.unique(st)).issubset({0, 1})
+    trusted = rec["oracle_valid"] & ~rec["degenerate"]
+    masked = int((~trusted).sum())
+    print("c2_big_%s: %d of %d records masked (uncertified %d, on the multiplier edge %d)"
+          % (tag, masked, len(st), int((~rec["oracle_valid"]).sum()), int(rec["degenerate"].sum())))
+    assert masked <= 10
+    feas = st == 0
+    assert np.array_equal(feas[trusted], rec["feasible"][trusted])
+    sel = trusted & feas
+    assert sel.sum() >= min_feasible
+    assert np.array_equal(res.active_mask()[sel], unpack_golden_active(rec, m)[sel])
+    assert _rel(res.numpy("argmin")[sel][:, :3], rec["argmin"][sel]) < RTOL
+    assert _rel(res.numpy("min")[sel], rec["min"][sel]) < RTOL
+    lam = res.numpy("multiplier_inequality")[sel]
+    scale = np.maximum(1.0, rec["multiplier_max"][sel])
+    assert np.max(np.abs(lam.max(axis=1) - rec["multiplier_max"][sel]) / scale) < RTOL
+    assert np.max(np.abs(lam.sum(axis=1) - rec["multiplier_sum"][sel]) / scale) < 10 * RTOL
+    # the masked records are judged by their own KKT residuals
+    for i in np.where(~trusted & feas)[0]:
+        sol = res.sol(int(i))
+        x = rec["X"][i]
+        f = model["Hux"].dot(x) + model["fu"]
+        b = model["b"] - model["Ax"].dot(x)
+        u, l = sol["argmin"], sol["multiplier_inequality"]
+        assert (model["Au"].dot(u) - b).max() < 1e-9 * max(1.0, np.abs(b).max())
+        assert l.min() >= 0.0
+        assert np.abs(model["Huu"].dot(u) + f + model["Au"].T.dot(l)).max() < 1e-7 * max(1.0, np.abs(l).max())
+    # how the batch was decided (lane path: at most kScreenStages columns and no drop; the rest by the wave kernel)
+    it = res.numpy("iters")
+    print("   decided with 0 / 1 / 2 / more columns: %d / %d / %d / %d feasible, %d infeasible"
+          % tuple([int((feas & (it[:, 0] == k)).sum()) for k in (0, 1, 2)] + [int((feas & (it[:, 0] > 2)).sum()), int((~feas).sum())]))
+
+
 def test_notebook_anchor():
     """examples/linear_mpc.ipynb cell 25: V*(x0 = [.39, .39]) = 100.8236250075..., u* = [-6, -6, -6, -6, -5.05.., -3.68..]."""
     model = golden("nb_model")

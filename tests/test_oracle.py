@@ -122,6 +122,24 @@ def test_oracle_nnls_vs_scipy_golden(oracle):
         assert abs(rn - float(g["r%d" % k])) < 1e-10
 
 
+@pytest.mark.parametrize("tag", ["s03", "s10"])
+def test_oracle_mpqp_vs_10k_reference_states(oracle, tag):
+    """SURVEY 8(d): 10 000 reference-run C2 states per distribution (compact records, make_golden.py::gen_c2big)."""
+    model = golden("c2_model"); rec = golden("c2_big_" + tag)
+    m = model["Au"].shape[0]
+    ob = oracle.mpqp_solve_batch(model, rec["X"])
+    trusted = rec["oracle_valid"] & ~rec["degenerate"]
+    assert (~trusted).sum() <= 10
+    feas = ob["status"] == 0
+    assert np.array_equal(feas[trusted], rec["feasible"][trusted])
+    sel = trusted & feas
+    assert np.array_equal(ob["active"][sel], unpack_golden_active(rec, m)[sel])
+    assert np.max(np.abs(ob["argmin"][sel][:, :3] - rec["argmin"][sel]) / np.maximum(1, np.abs(rec["argmin"][sel]))) < 1e-6
+    assert np.max(np.abs(ob["min"][sel] - rec["min"][sel]) / np.maximum(1, np.abs(rec["min"][sel]))) < 1e-6
+    lam = ob["multiplier_inequality"][sel]
+    assert np.max(np.abs(lam.max(axis=1) - rec["multiplier_max"][sel]) / np.maximum(1, rec["multiplier_max"][sel])) < 1e-6
+
+
 @pytest.mark.parametrize("model_name,solve_name", [("c1_model", "c1_solves"), ("nb_model", "nb_solves"),
                                                    ("c2_model", "c2_solves_s03"), ("c2_model", "c2_solves_s10")])
 def test_oracle_mpqp_vs_reference_golden(oracle, model_name, solve_name):

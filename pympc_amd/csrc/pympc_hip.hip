@@ -138,12 +138,13 @@ int check_shape(int n, int m, int p)
 }
 
 // Learning pre-pass of a large shared-matrix batch with a certificate table: kLearnStates states, taken at a constant
-// stride over the batch, are solved first with ONE wavefront per SIMD (a full infeasible solve is a serial chain of
-// ~24 pivots: alone on its SIMD it runs three times faster than beside two others), so that the table holds the
+// stride over the batch, are solved first by the wave kernel alone (no screening pass: its three serial sweeps cost
+// more latency than the few states are worth), at most three states per wavefront, so that the table holds the
 // certificates of the batch's infeasible regions before the main launch starts.  Without it every wave of the main
-// launch meets its first infeasible state with an empty table and solves it in full at the same time as all others.
-// The pre-pass writes no outputs: its statuses go to the head of the caller's status array, which the main launch
-// overwrites.  With a table that is already warm it finds nothing to learn and costs two nearly empty launches.
+// launch meets its first infeasible state with an empty table and solves it in full (a serial chain of ~24 pivots)
+// at the same time as all the others.  The pre-pass writes no outputs: its statuses go to the head of the caller's
+// status array, which the main launch overwrites.  With a table that is already warm its infeasible states are
+// rejected at once and it costs one short launch.
 constexpr long long kLearnMinBatch = 131072;
 constexpr long long kLearnStates = 8192;
 
@@ -162,6 +163,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         const long long step = P.B / kLearnStates;
         A.B = kLearnStates;
         A.x_stride = (long long)p * step;
+        A.learn = 1;
         A.argmin = nullptr; A.vmin = nullptr; A.mult = nullptr; A.active = nullptr; A.iters = nullptr;
         if (int rc = solve_common(true, n, m, p, A, st, true)) return rc;
     }
@@ -178,7 +180,6 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     const int max_waves = mt <= 8 ? 12 : 4;   // = solve_max_waves<MT>() (launch bounds of the kernel)
     const int cap = shared ? max_waves : 4;
     if (nwaves > cap) nwaves = cap;
-    if (learn_pass && nwaves > 4) nwaves = 4;   // one wavefront per SIMD
     if (shared && nwaves > 4) nwaves &= ~3;   // a multiple of the 4 SIMDs
     if ((long long)nwaves > P.B) nwaves = (int)P.B;
     if (nwaves < 1) nwaves = 1;
@@ -190,7 +191,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         // smaller ones below that so that every wave still has work
         int ncu = cu_count();
         if (ncu <= 0) ncu = 256;
-        chunk = learn_pass ? 2 : 8;
+        chunk = learn_pass ? 1 : 8;
         while (chunk > 1 && P.B < chunk * nwaves * ncu) chunk >>= 1;
         const long long nslice = (P.B + chunk - 1) / chunk;
         const long long want = (nslice + nwaves - 1) / nwaves;   // workgroups that still give every wave a slice
@@ -200,7 +201,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         P.chunk = (int)chunk;
         // screening pass: states with a feasible unconstrained minimiser (and those a stored certificate rejects) finish here
         P.screened = 0;
-        if (p >= 1 && p <= 8 && P.x_stride >= p && P.B <= 0x7fffffffLL) {
+        if (!learn_pass && p >= 1 && p <= 8 && P.x_stride >= p && P.B <= 0x7fffffffLL) {
             P.screened = 1;
             // persistent workgroups, two per CU, each walking over whole tiles of states (qp_screen.hpp); the grid is
             // evened out so that every workgroup gets the same number of tiles (+- 1)

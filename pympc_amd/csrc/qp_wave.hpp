@@ -55,6 +55,7 @@ struct SolveParams {
     int screened;               // SHARED: status[] was initialised by mpqp_screen_kernel (kStatusPending = still to solve)
     int persist;                // SHARED: the grid is one workgroup per CU, workgroup g owns slices g, g + G, g + 2 G, ...
     int wave_doubles;           // per-wave LDS doubles
+    int learn;                  // SHARED: this launch is the certificate-learning pre-pass (returns at once if the table is not empty)
     double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
     const double *gram;         // SHARED: Gram matrix of the constant rows [mp x mp] (ws_layout.hpp) or null
 };
@@ -96,6 +97,7 @@ constexpr int kCutPMax = 8;
 constexpr int kCutHeader = 2;
 constexpr double kCutMargin = 1e-6;
 constexpr double kCutVerify = 1e-11;
+constexpr int kCutLearnSkip = 16;    // entries from which the learning pre-pass of a launch is skipped
 constexpr int kCutRecheckFrom = 6;   // passive columns from which a running solve looks at newly stored certificates
 __host__ __device__ inline size_t cut_table_doubles(int p) { return kCutHeader + (size_t)(p + 1) * kCutMax; }
 
@@ -609,6 +611,8 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
     extern __shared__ double lds[];
     constexpr int mp = 64 * MT;
     const int n = P.n, p = P.p;
+    // learning pre-pass: a table that already holds certificates (kept from an earlier call) needs none
+    if (SHARED && P.learn && P.cuts && cut_count(P.cuts) >= kCutLearnSkip) return;
     const SharedLds S_ = shared_lds(n, P.L);
     const size_t sharedD = SHARED ? S_.total : 0;
     int *ticket = reinterpret_cast<int *>(lds + sharedD);

@@ -195,6 +195,29 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
                          void *stream);
 
 /* -------------------------------------------------------------------------------------------------
+ * Raw NNLS and PNNLS: the two numerical cores under the QP / LP transformations.
+ *
+ * pympc_nnls_batch: B problems  min |A_k x - b_k|  s.t. x >= 0  of equal shape (rows <= 64, cols <= 2048).
+ * Reference: scipy.optimize.nnls(A, b) as called at pympc/optimization/solvers/pnnls.py:36 and :218 (third party,
+ * pinned scipy<=1.11.4: Lawson-Hanson; maxiter = 3 cols).  A [B x rows x cols] (a_stride = rows*cols) or [rows x cols]
+ * shared (a_stride 0); b [B x rows].  Outputs x [B x cols], rnorm [B] = |A x - b| (may be NULL), status [B]
+ * (PYMPC_OPTIMAL / PYMPC_MAXITER: scipy raises RuntimeError there), iters [B x 2] (may be NULL).
+ *
+ * pympc_pnnls_batch: B problems  min |A_k v + B_k u - c_k|  s.t. v >= 0  (rows <= 64, cols <= 2048, nu <= 64).
+ * Reference: pnnls(A, B, c) of pympc/optimization/solvers/pnnls.py:5-39 (returns v, u, r); the reference projects
+ * with the dense matrix I - B pinv(B) (:30-33), here u is eliminated by a column-pivoted Householder QR of B (same
+ * residual; u is the minimum-norm solution when B is rank deficient, as pinv gives).  A [B x rows x cols],
+ * Bm [B x rows x nu], c [B x rows].  Outputs v [B x cols], u [B x nu], rnorm [B] (may be NULL), status, iters as above.
+ * ws: *_workspace_doubles(...) doubles of device scratch.
+ * ------------------------------------------------------------------------------------------------- */
+size_t pympc_nnls_workspace_doubles(int rows, int cols, int64_t B);
+int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_stride, const double *b, double *ws, double *x,
+                     double *rnorm, int32_t *status, int32_t *iters, void *stream);
+size_t pympc_pnnls_workspace_doubles(int rows, int cols, int nu, int64_t B);
+int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, const double *Bm, const double *c, double *ws,
+                      double *v, double *u, double *rnorm, int32_t *status, int32_t *iters, void *stream);
+
+/* -------------------------------------------------------------------------------------------------
  * Explicit-MPC point location + affine law: first critical region (list order) containing each point.
  * Reference: pympc/optimization/parametric_programs.py:442-463 (get_critical_region), :465-532 (u, V),
  * :349-400 (CriticalRegion.u / V), pympc/geometry/polyhedron.py:578-604 (contains, tol 1e-7).

@@ -69,6 +69,19 @@ def nnls(A, b):
     return x, rn.value, (int(it[0]), int(it[1]))
 
 
+def pnnls(A, B, c):
+    """pnnls.py:5-39: (v, u, r)."""
+    A = _d(A); B = _d(B); c = _d(c)
+    rows, nv = A.shape
+    nu = B.shape[1]
+    v = np.zeros(nv); u = np.zeros(max(nu, 1)); rn = ctypes.c_double(0.0); it = np.zeros(2, np.int32)
+    st = lib().oracle_pnnls(_p(A), _p(B), _p(c), ctypes.c_int(rows), ctypes.c_int(nv), ctypes.c_int(nu), _p(v), _p(u),
+                            ctypes.byref(rn), _pi(it))
+    if st == MAXITER:
+        raise RuntimeError("Maximum number of iterations reached.")
+    return v, u[:nu], rn.value
+
+
 def _empty_sol():
     return {'min': None, 'argmin': None, 'active_set': None, 'multiplier_inequality': None, 'multiplier_equality': None}
 

@@ -30,6 +30,10 @@ SIGNATURES = {
     "pympc_mpqp_cuts_reset": (_i, [_i, _vp, _vp]),
     "pympc_mpqp_solve_batch_cuts": (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pympc_mpqp_solve_batch_static": (_i, [_i, _i, _i, _vp, _vp, _i64, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pympc_nnls_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i64]),
+    "pympc_nnls_batch": (_i, [_i, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pympc_pnnls_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i, _i64]),
+    "pympc_pnnls_batch": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pympc_qp_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i64]),
     "pympc_qp_solve_batch": (_i, [_i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp]),

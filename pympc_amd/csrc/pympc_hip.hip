@@ -11,6 +11,7 @@
 #include "condense.hpp"
 #include "lp_block.hpp"
 #include "lp_tile.hpp"
+#include "nnls_raw.hpp"
 #include "point_location.hpp"
 #include "qp_prepare.hpp"
 #include "qp_wave.hpp"
@@ -257,7 +258,7 @@ int scratch_address(double **out)
 
 extern "C" {
 
-int pympc_hip_abi_version(void) { return 5; }   // 5: the prepared mpQP workspace carries the Gram matrix
+int pympc_hip_abi_version(void) { return 6; }   // 6: pympc_nnls_batch, pympc_pnnls_batch, pympc_mpqp_solve_batch_static
 
 const char *pympc_hip_last_error(void) { return g_err; }
 
@@ -355,6 +356,93 @@ int pympc_mpqp_solve_batch_static(int n, int m, int p, const double *ws, const d
     hipError_t e = hipMemsetAsync(table, 0, cut_table_doubles(p) * sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipMemsetAsync(static scratch): %s", hipGetErrorString(e));
     return pympc_mpqp_solve_batch_cuts(n, m, p, ws, table, X, B, tol, n_out, argmin, vmin, mult, active, status, iters, stream);
+}
+
+// ---- raw NNLS / PNNLS (nnls_raw.hpp)
+size_t pympc_nnls_workspace_doubles(int rows, int cols, int64_t B)
+{
+    const int R = rows < 2 ? 2 : rows;
+    if (rows < 1 || cols < 1 || R - 1 > kNMax || cols > kMMax || B < 0) return 0;
+    return (ws_layout(R - 1, cols, 0).total + (size_t)R) * (size_t)B + 32;
+}
+
+int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_stride, const double *b, double *ws, double *x,
+                     double *rnorm, int32_t *status, int32_t *iters, void *stream)
+{
+    if (rows < 1 || cols < 1 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_nnls_batch: bad shape %d x %d", rows, cols);
+    const int R = rows < 2 ? 2 : rows;
+    if (R - 1 > kNMax) return fail(PYMPC_ERR_UNSUPPORTED, "rows=%d exceeds the wave kernel's limit of %d rows", rows, kNMax + 1);
+    if (cols > kMMax) return fail(PYMPC_ERR_UNSUPPORTED, "cols=%d exceeds the wave kernel's limit of %d columns", cols, kMMax);
+    if (a_stride != 0 && a_stride < (int64_t)rows * cols) return fail(PYMPC_ERR_ARG, "a_stride %lld < rows*cols", (long long)a_stride);
+    if (B == 0) return 0;
+    if (!A || !b || !ws || !x || !status) return fail(PYMPC_ERR_ARG, "pympc_nnls_batch: null pointer");
+    if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    const WsLayout L = ws_layout(R - 1, cols, 0);
+    NnlsPrepParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.rows = rows; Q.cols = cols; Q.L = L; Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = rows;
+    Q.ws = ws; Q.rhs = ws + L.total * (size_t)B;
+    hipLaunchKernelGGL(nnls_prepare_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, Q);
+    if (int rc = check_launch("nnls_prepare_kernel")) return rc;
+    SolveParams P;
+    memset(&P, 0, sizeof(P));
+    P.ws = ws; P.ws_stride = (long long)L.total; P.B = B; P.tol = 0.0; P.n_out = 0;
+    P.vmin = rnorm; P.mult = x; P.status = status; P.iters = iters;
+    P.rhs = Q.rhs; P.rhs_stride = R; P.raw = 1;
+    return solve_common(false, R - 1, cols, 0, P, (hipStream_t)stream);
+}
+
+size_t pympc_pnnls_workspace_doubles(int rows, int cols, int nu, int64_t B)
+{
+    if (rows < 1 || rows > 64 || cols < 1 || cols > kMMax || nu < 0 || nu > 64 || B < 0) return 0;
+    const size_t nn = pympc_nnls_workspace_doubles(rows, cols, B);
+    if (nn == 0) return 0;
+    return nn + ((size_t)rows * cols + rows + (size_t)rows * nu + nu + 2) * (size_t)B + 32;
+}
+
+int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, const double *Bm, const double *c, double *ws,
+                      double *v, double *u, double *rnorm, int32_t *status, int32_t *iters, void *stream)
+{
+    if (rows < 1 || cols < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: bad shape");
+    if (rows > 64 || nu > 64 || cols > kMMax)
+        return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of 64 rows, 64 free and %d sign-constrained variables",
+                    rows, cols, nu, kMMax);
+    if (B == 0) return 0;
+    if (!A || !c || !ws || !v || !status || (nu > 0 && (!Bm || !u))) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: null pointer");
+    if (nu == 0) return pympc_nnls_batch(rows, cols, B, A, (int64_t)rows * cols, c, ws, v, rnorm, status, iters, stream);
+    if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    const size_t nn = pympc_nnls_workspace_doubles(rows, cols, B);
+    PnnlsParams R;
+    memset(&R, 0, sizeof(R));
+    R.rows = rows; R.cols = cols; R.nu = nu; R.A = A; R.Bm = Bm; R.c = c;
+    R.QA = ws + nn;
+    R.Qc = R.QA + (size_t)rows * cols * B;
+    R.Rf = R.Qc + (size_t)rows * B;
+    R.perm = reinterpret_cast<int32_t *>(R.Rf + (size_t)rows * nu * B);
+    R.rank = R.perm + (size_t)nu * B;
+    R.v = v; R.u = u;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds1 = pnnls_lds_doubles(rows, nu) * 8;
+    hipLaunchKernelGGL(pnnls_reduce_kernel, dim3((unsigned)B), dim3(64), lds1, st, R);
+    if (int rc = check_launch("pnnls_reduce_kernel")) return rc;
+    // NNLS in v on the rows the reflectors left free of u (pnnls.py:36)
+    const int Rr = rows < 2 ? 2 : rows;
+    const WsLayout L = ws_layout(Rr - 1, cols, 0);
+    NnlsPrepParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.rows = rows; Q.cols = cols; Q.L = L; Q.A = R.QA; Q.a_stride = (long long)rows * cols; Q.b = R.Qc; Q.b_stride = rows;
+    Q.skip_rows = R.rank; Q.ws = ws; Q.rhs = ws + L.total * (size_t)B;
+    hipLaunchKernelGGL(nnls_prepare_kernel, dim3((unsigned)B), dim3(256), 0, st, Q);
+    if (int rc = check_launch("nnls_prepare_kernel")) return rc;
+    SolveParams P;
+    memset(&P, 0, sizeof(P));
+    P.ws = ws; P.ws_stride = (long long)L.total; P.B = B; P.tol = 0.0; P.n_out = 0;
+    P.vmin = rnorm; P.mult = v; P.status = status; P.iters = iters;
+    P.rhs = Q.rhs; P.rhs_stride = Rr; P.raw = 1;
+    if (int rc = solve_common(false, Rr - 1, cols, 0, P, st)) return rc;
+    // u = -pinv(B) (A v - c) (pnnls.py:37)
+    hipLaunchKernelGGL(pnnls_recover_kernel, dim3((unsigned)B), dim3(64), (64 + 64 * 65 + 64) * 8, st, R);
+    return check_launch("pnnls_recover_kernel");
 }
 
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)

@@ -55,6 +55,11 @@ struct SolveParams {
     int screened;               // SHARED: status[] was initialised by mpqp_screen_kernel (kStatusPending = still to solve)
     int persist;                // SHARED: the grid is one workgroup per CU, workgroup g owns slices g, g + G, g + 2 G, ...
     int wave_doubles;           // per-wave LDS doubles
+    // raw NNLS (pympc_nnls_batch: scipy.optimize.nnls on a general matrix and right-hand side): rhs [B x (n + 1)] replaces
+    // e_R, the outputs are the coefficients (mult [B x m]) and the residual norm (vmin [B]); no QP interpretation
+    const double *rhs;
+    long long rhs_stride;
+    int raw;
     int learn;                  // SHARED: this launch is the certificate-learning pre-pass (returns at once if the table is not empty)
     double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
     const double *gram;         // SHARED: Gram matrix of the constant rows [mp x mp] (ws_layout.hpp) or null
@@ -235,7 +240,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     double *rb = wl + invqr_lds_doubles(R, RP);
     double *x0 = rb + R + kVecPad;   // the parameter vector, staged once and followed by 8 zeros (LDS broadcasts later on)
     if (lane < p) x0[lane] = P.X[prob * P.x_stride + lane];
-    if (lane < R) F.cv[lane] = (lane == n) ? 1.0 : 0.0;   // cv = Qt e_R with Qt = I
+    if (lane < R) F.cv[lane] = P.rhs ? P.rhs[prob * P.rhs_stride + lane] : ((lane == n) ? 1.0 : 0.0);   // cv = Qt b, Qt = I
     const int ncut = P.cuts ? cut_count(P.cuts) : 0;
     wave_sync_lds();
 
@@ -313,11 +318,12 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 
     while (status == kStatusOptimal && k < R && k < m) {
         // ---------------- dual sweep  w = A'(b - A y) = A' Qt'[0; cv[k:]]
-        if (!qt_ready) {
+        if (!qt_ready && !P.rhs) {
 #pragma unroll
-            for (int s = 0; s < MT; ++s) w[s] = -mv[s];
+            for (int s = 0; s < MT; ++s) w[s] = -mv[s];   // A'e_R: the last row
         } else {
-            if (lane < R) rb[lane] = dotu(F.Q + lane * RP + k, F.cv + k, R - k);   // r = Qt'[0; cv[k:]]
+            // r = Qt'[0; cv[k:]]  (before the first column enters: Qt = I, r = the right-hand side)
+            if (lane < R) rb[lane] = qt_ready ? dotu(F.Q + lane * RP + k, F.cv + k, R - k) : F.cv[lane];
             wave_sync_lds();
             double acc[MT];
             const double rn = rb[n];
@@ -497,15 +503,15 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     // Three sums in one butterfly: the squared NNLS residual |cv[k:]|^2, m'y, and the unconstrained value V_unc(x).
     const WsLayout &L = P.L;
     double r2 = 0.0, my = 0.0, vq = 0.0;
-    if (qt_ready && lane >= k && lane < R) {
+    if ((qt_ready || P.rhs) && lane >= k && lane < R) {
         const double cl = F.cv[lane];
         r2 = cl * cl;
     }
     if (lane < k) my = mPl * yl;
     if (P.vmin && lane < p) vq = x0[lane] * fma(0.5, dotu(tab + L.Sxx + lane * p, x0, p), tab[L.sx + lane]);
     wsum3(r2, my, vq);
-    const double rnorm = qt_ready ? fast_sqrt(r2) : fast_sqrt(virt ? r2v : 1.0);   // Qt = I, cv = e_R before the first column enters
-    if (status == kStatusOptimal && !(rnorm > P.tol)) {
+    const double rnorm = (qt_ready || P.rhs) ? fast_sqrt(r2) : fast_sqrt(virt ? r2v : 1.0);   // Qt = I, cv = e_R before the first column enters
+    if (!P.raw && status == kStatusOptimal && !(rnorm > P.tol)) {
         status = kStatusInfeasible;
         if (P.cuts && k > 0) cut_learn(P.cuts, n, p, mp, Mt, mtp, m0, Gm, k, Pl, yl, mPl, x0);
     }
@@ -515,7 +521,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 
     // lambda = y / (1 + m'y) (pnnls.py:231).  With gamma = 1 + m'y the optimal value needs nothing else: the NNLS
     // optimality conditions give |M'y|^2 = -m'y gamma, hence V - V_unc = .5 |L^-1 A_P'lambda|^2 = -.5 m'y / gamma.
-    const double ginv = okk ? fast_div(1.0, 1.0 + my) : 0.0;
+    const double ginv = P.raw ? 1.0 : (okk ? fast_div(1.0, 1.0 + my) : 0.0);
     const double lam = (lane < k) ? yl * ginv : 0.0;
     if (P.argmin) {
         double ui = nanv;
@@ -538,7 +544,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
         }
         if (lane < P.n_out) P.argmin[prob * P.n_out + lane] = ui;
     }
-    if (P.vmin && lane == 0) P.vmin[prob] = okk ? (tab[L.s0] + vq) - 0.5 * my * ginv : nanv;
+    if (P.vmin && lane == 0) P.vmin[prob] = P.raw ? rnorm : (okk ? (tab[L.s0] + vq) - 0.5 * my * ginv : nanv);
 #ifndef PYMPC_PHASE_TIMING   // (the debug build reports its cycle counts through mult)
     if (P.mult) {
 #pragma unroll

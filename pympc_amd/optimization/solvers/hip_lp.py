@@ -5,6 +5,11 @@ Mirrors /root/reference/pympc/optimization/solvers/pnnls.py:41-147:
 plus the batched form the reference does not have (its callers loop in Python, e.g. polyhedron.py:435-448):
     linear_program_batch(f, A, b, relax_idx=None, relax_val=0., ...)   B LPs of equal shape in one launch
 
+and the two numerical cores as callables of the backend (module contract of pnnls.py: three public functions):
+    pnnls(A, B, c)               pnnls.py:5-39    -> (v, u, r)
+    nnls(A, b)                   scipy.optimize.nnls as called at pnnls.py:36,218 -> (x, rnorm)
+with batched forms pnnls_batch / nnls_batch.
+
 Result contract (pnnls.py:128-145): dict with keys min, argmin, active_set, multiplier_inequality,
 multiplier_equality; every value None when the LP is infeasible or unbounded.
 """
@@ -75,3 +80,68 @@ def linear_program(f, A, b, C=None, d=None, tol=TOL):
         AC, bd = A, b
     res = linear_program_batch(f[None, :], AC, bd, tol=tol, n_eq=n_eq)
     return res.sol(0)
+
+
+def nnls_batch(A, b):
+    """B NNLS problems min |A_k x - b_k|, x >= 0 in one launch.  A: [rows x cols] (shared) or [B x rows x cols];
+    b: [B x rows].  Returns device tensors (x [B x cols], rnorm [B], status [B])."""
+    lib = _hip.load_library()
+    dev = _hip.device()
+    A = _hip.to_device(A); b = _hip.to_device(b)
+    if b.dim() != 2 or A.dim() not in (2, 3) or A.shape[-2] != b.shape[1] or (A.dim() == 3 and A.shape[0] != b.shape[0]):
+        raise ValueError('incoherent size of the inputs.')
+    B, rows = b.shape
+    cols = A.shape[-1]
+    nd = lib.pympc_nnls_workspace_doubles(rows, cols, B)
+    if nd == 0:
+        raise NotImplementedError('NNLS with %d rows, %d columns is outside the wave kernel limits (64 rows, 2048 columns)'
+                                  % (rows, cols))
+    ws = torch.empty(nd, dtype=torch.float64, device=dev)
+    x = torch.empty((B, cols), dtype=torch.float64, device=dev)
+    rn = torch.empty(B, dtype=torch.float64, device=dev)
+    st = torch.empty(B, dtype=torch.int32, device=dev)
+    _hip.check(lib.pympc_nnls_batch(rows, cols, B, _hip.ptr(A), 0 if A.dim() == 2 else rows * cols, _hip.ptr(b), _hip.ptr(ws),
+                                    _hip.ptr(x), _hip.ptr(rn), _hip.ptr(st), None, _hip.stream_ptr()))
+    return x, rn, st
+
+
+def nnls(A, b):
+    """scipy.optimize.nnls(A, b) on the GPU: (x, rnorm); RuntimeError at the iteration limit like scipy."""
+    A = np.asarray(A, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    x, rn, st = nnls_batch(A, b[None, :])
+    if int(st.item()) == _hip.MAXITER:
+        raise RuntimeError('Maximum number of iterations reached.')
+    return x[0].cpu().numpy(), float(rn.item())
+
+
+def pnnls_batch(A, B, c):
+    """B PNNLS problems min |A_k v + B_k u - c_k|, v >= 0 (pnnls.py:5-39) in one launch.  A [Bn x rows x cols],
+    B [Bn x rows x nu], c [Bn x rows].  Returns device tensors (v, u, r, status)."""
+    lib = _hip.load_library()
+    dev = _hip.device()
+    A = _hip.to_device(A); Bm = _hip.to_device(B); c = _hip.to_device(c)
+    if A.dim() != 3 or Bm.dim() != 3 or c.dim() != 2 or A.shape[:2] != Bm.shape[:2] or A.shape[:2] != c.shape:
+        raise ValueError('incoherent size of the inputs.')
+    Bn, rows, cols = A.shape
+    nu = Bm.shape[2]
+    nd = lib.pympc_pnnls_workspace_doubles(rows, cols, nu, Bn)
+    if nd == 0:
+        raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (64 rows, 2048 + 64)'
+                                  % (rows, cols, nu))
+    ws = torch.empty(nd, dtype=torch.float64, device=dev)
+    v = torch.empty((Bn, cols), dtype=torch.float64, device=dev)
+    u = torch.empty((Bn, nu), dtype=torch.float64, device=dev)
+    rn = torch.empty(Bn, dtype=torch.float64, device=dev)
+    st = torch.empty(Bn, dtype=torch.int32, device=dev)
+    _hip.check(lib.pympc_pnnls_batch(rows, cols, nu, Bn, _hip.ptr(A), _hip.ptr(Bm), _hip.ptr(c), _hip.ptr(ws), _hip.ptr(v),
+                                     _hip.ptr(u), _hip.ptr(rn), _hip.ptr(st), None, _hip.stream_ptr()))
+    return v, u, rn, st
+
+
+def pnnls(A, B, c):
+    """Drop-in for pnnls.pnnls (pnnls.py:5-39): (v, u, r) with v >= 0 minimising |A v + B u - c|, r the residual."""
+    A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); c = np.asarray(c, dtype=np.float64)
+    v, u, rn, st = pnnls_batch(A[None], B[None], c[None])
+    if int(st.item()) == _hip.MAXITER:
+        raise RuntimeError('Maximum number of iterations reached.')
+    return v[0].cpu().numpy(), u[0].cpu().numpy(), float(rn.item())

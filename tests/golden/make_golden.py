@@ -411,6 +411,44 @@ def gen_nnls():
     np.savez_compressed(os.path.join(HERE, "nnls_cases.npz"), **out)
 
 
+def gen_scipynnls():
+    """The NNLS regression problems of the container's scipy (scipy/optimize/tests/test_nnls.py, SURVEY 8c: gh-20168,
+    gh-20302, gh-21021 ...): the test methods are RUN with a recording nnls, so the file holds the matrices they build,
+    scipy's answers and the KKT certificate of each answer.  (Third-party fixtures, not reference code.)"""
+    print("scipy's own NNLS regression problems")
+    import scipy.optimize.tests.test_nnls as T
+    rec = []
+    real = T.nnls
+
+    def recorder(A, b, *args, **kw):
+        A = np.asarray(A, dtype=float); b = np.asarray(b, dtype=float)
+        x, rn = real(A, b, *args, **kw)
+        ok, _ = nnls_certificate(A, b, x, rn)
+        rec.append((A.copy(), b.copy(), x, rn, ok, bool(args or kw)))
+        return x, rn
+
+    T.nnls = recorder
+    t = T.TestNNLS()
+    names = []
+    for name in sorted(dir(t)):
+        if not name.startswith("test_") or name == "test_maxiter":
+            continue
+        t.setup_method()
+        n0 = len(rec)
+        try:
+            getattr(t, name)()
+        except AssertionError:
+            pass
+        names += [name] * (len(rec) - n0)
+    T.nnls = real
+    out = dict(count=np.asarray(len(rec)), names=np.array(names))
+    for k, (A, b, x, rn, ok, custom) in enumerate(rec):
+        out["A%d" % k] = A; out["b%d" % k] = b; out["x%d" % k] = x; out["r%d" % k] = np.asarray(rn)
+        out["ok%d" % k] = np.asarray(ok)
+        print("  %-32s %3d x %3d certified %s" % (names[k], A.shape[0], A.shape[1], ok))
+    np.savez_compressed(os.path.join(HERE, "scipy_nnls_tests.npz"), **out)
+
+
 def gen_hybrid():
     """Config C5 anchors: get_mpqp(mode_sequence).solve(x0) for a handful of mode sequences (N=10)."""
     print("hybrid cart-pole fixed-mode-sequence QPs (N=10)")
@@ -491,8 +529,8 @@ def gen_bigm():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="c1,c2,c2big,ctrl,nb,lp,nnls,hybrid,bigm")
+    ap.add_argument("--only", default="c1,c2,c2big,ctrl,nb,lp,nnls,scipynnls,hybrid,bigm")
     only = ap.parse_args().only.split(",")
-    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("c2big", gen_c2big), ("ctrl", gen_ctrl), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("hybrid", gen_hybrid), ("bigm", gen_bigm)):
+    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("c2big", gen_c2big), ("ctrl", gen_ctrl), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("scipynnls", gen_scipynnls), ("hybrid", gen_hybrid), ("bigm", gen_bigm)):
         if name in only:
             fn()

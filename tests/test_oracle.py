@@ -122,6 +122,36 @@ def test_oracle_nnls_vs_scipy_golden(oracle):
         assert abs(rn - float(g["r%d" % k])) < 1e-10
 
 
+def test_oracle_nnls_vs_scipy_regression_problems(oracle):
+    """scipy's own NNLS regression problems (scipy/optimize/tests/test_nnls.py, recorded by make_golden.py)."""
+    g = golden("scipy_nnls_tests")
+    n = 0
+    for k in range(int(g["count"])):
+        if not bool(g["ok%d" % k]):
+            continue
+        A, b = g["A%d" % k], g["b%d" % k]
+        x, rn, _ = oracle.nnls(A, b)
+        scale = max(1.0, np.abs(g["x%d" % k]).max())
+        assert np.allclose(x, g["x%d" % k], rtol=0, atol=1e-8 * scale), str(g["names"][k])
+        assert abs(rn - float(g["r%d" % k])) < 1e-8 * max(1.0, np.linalg.norm(b))
+        n += 1
+    assert n >= 6
+
+
+def test_oracle_pnnls_against_numpy_restatement(oracle):
+    """pnnls(A, B, c) (pnnls.py:5-39): the projector formulation written out with numpy + the golden-certified nnls."""
+    rng = np.random.RandomState(5)
+    for rows, nv, nu in ((6, 4, 2), (12, 16, 3), (9, 20, 4), (8, 3, 5)):
+        A = rng.randn(rows, nv); B = rng.randn(rows, nu); c = rng.randn(rows)
+        v, u, r = oracle.pnnls(A, B, c)
+        Bp = np.linalg.pinv(B)
+        Bbar = np.eye(rows) - B.dot(Bp)
+        v2, r2, _ = oracle.nnls(Bbar.dot(A), Bbar.dot(c))
+        assert np.allclose(v, v2, atol=1e-10) and abs(r - r2) < 1e-10
+        assert np.allclose(u, -Bp.dot(A.dot(v) - c), atol=1e-10)
+        assert abs(np.linalg.norm(A.dot(v) + B.dot(u) - c) - r) < 1e-9
+
+
 @pytest.mark.parametrize("tag", ["s03", "s10"])
 def test_oracle_mpqp_vs_10k_reference_states(oracle, tag):
     """SURVEY 8(d): 10 000 reference-run C2 states per distribution (compact records, make_golden.py::gen_c2big)."""

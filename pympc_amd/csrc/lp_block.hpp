@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
             k = ctl[3];
             status = ctl[4];
             if (ctl[2]) { accepted = true; break; }
-            if (ctl[1] > kLpRejMax) break;
+            if (ctl[1] > kLpRejMax) break;   // (ctl[1] keeps telling so below: candidates with a positive dual remain untried)
         }
         if (!accepted || status != kStatusOptimal) break;
     }
@@ -288,7 +288,9 @@ __global__ void __launch_bounds__(1024) lp_solve_kernel(LpParams P)
     if (wave == 0 && status == kStatusOptimal) {
         const double cl = (lane >= k && lane < n) ? F.cv[lane] : 0.0;
         const double rn = sqrt(wsum(cl * cl));
-        if (!(rn < P.tol)) status = kStatusInfeasible;   // no dual feasible point: LP unbounded or infeasible
+        // no dual feasible point: LP unbounded or infeasible -- unless phase 1 stopped at its cap of rejected candidates:
+        // then nothing is proven and the host raises (iteration limit) instead of answering None
+        if (!(rn < P.tol)) status = (ctl[1] > kLpRejMax) ? kStatusMaxIter : kStatusInfeasible;
         if (lane == 0) ctl[4] = status;
     }
     __syncthreads();

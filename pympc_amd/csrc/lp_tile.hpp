@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(64 * kLpTileWaves, PYMPC_LPT_WAVES_PER_SIMD) l
     int mode = kLpIdle;
     long long prob = -1;
     int rx = -1, k = 0, status = kStatusOptimal, outer = 0, inner = 0, piv = 0, nrej = 0;
+    bool capped = false;
     int Wl = -1;
     double yl = 0.0, fnorm = 1.0;
     double arx = 0.0, brx = 0.0, airx = 1.0;   // relaxed row: lane i < n holds its i-th entry; right-hand side; 1 / norm
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(64 * kLpTileWaves, PYMPC_LPT_WAVES_PER_SIMD) l
                     F.cv[lane] = -f[lane];
                 }
                 wave_sync_lds();
-                k = 0; status = kStatusOptimal; outer = 0; inner = 0; piv = 0; nrej = 0; Wl = -1; yl = 0.0;
+                k = 0; status = kStatusOptimal; outer = 0; inner = 0; piv = 0; nrej = 0; capped = false; Wl = -1; yl = 0.0;
                 const double fl = (lane < n) ? F.cv[lane] : 0.0;
                 const double fn = sqrt(wsum(fl * fl));
                 fnorm = fmax(1.0, fn);
@@ -345,6 +346,7 @@ __global__ void __launch_bounds__(64 * kLpTileWaves, PYMPC_LPT_WAVES_PER_SIMD) l
                         ++nrej;
                     } else {
                         p1_end = true;
+                        capped = true;   // candidates with a positive dual remain untried
                     }
                 }
             }
@@ -352,7 +354,9 @@ __global__ void __launch_bounds__(64 * kLpTileWaves, PYMPC_LPT_WAVES_PER_SIMD) l
                 const double cl = (lane >= k && lane < n) ? F.cv[lane] : 0.0;
                 const double rn = sqrt(wsum(cl * cl));
                 if (!(rn < P.tol)) {
-                    status = kStatusInfeasible;   // no dual feasible point: LP unbounded or infeasible
+                    // no dual feasible point: LP unbounded or infeasible -- unless phase 1 stopped at its cap of rejected
+                    // candidates, then nothing is proven and the host raises (iteration limit) instead of answering None
+                    status = capped ? kStatusMaxIter : kStatusInfeasible;
                     finish = true;
                 } else {
                     mode = kLpPhase2;

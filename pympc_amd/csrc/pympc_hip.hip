@@ -135,6 +135,16 @@ int check_shape(int n, int m, int p)
     if (n < 1 || m < 1 || p < 0) return fail(PYMPC_ERR_ARG, "bad shape n=%d m=%d p=%d", n, m, p);
     if (n > kNMax) return fail(PYMPC_ERR_UNSUPPORTED, "n=%d exceeds the wave kernel's limit of %d variables", n, kNMax);
     if (m > kMMax) return fail(PYMPC_ERR_UNSUPPORTED, "m=%d exceeds the wave kernel's limit of %d rows", m, kMMax);
+    if (p > kPMax) return fail(PYMPC_ERR_UNSUPPORTED, "p=%d exceeds the wave kernel's limit of %d parameters", p, kPMax);
+    return 0;
+}
+
+// the prepare workgroup keeps its factor matrices and Hux in LDS: refuse shapes that do not fit instead of failing at launch
+int check_prep(const PrepGeom &G, int n, int m, int p)
+{
+    if (G.lds_bytes > kLdsBytes)
+        return fail(PYMPC_ERR_UNSUPPORTED, "factorisation of a %dx%d QP with p=%d parameters needs %zu B of LDS (160 KiB available)",
+                    n, m, p, G.lds_bytes);
     return 0;
 }
 
@@ -270,7 +280,8 @@ void pympc_hip_limits(int *n_max, int *m_max)
 
 size_t pympc_mpqp_workspace_doubles(int n, int m, int p)
 {
-    if (n < 1 || m < 1 || p < 0 || n > kNMax || m > kMMax) return 0;
+    if (n < 1 || m < 1 || p < 0 || n > kNMax || m > kMMax || p > kPMax) return 0;
+    if (prep_geom(n, m, p).lds_bytes > kLdsBytes) return 0;
     const WsLayout L = ws_layout(n, m, p);
     return L.total + ws_gram_doubles(L);
 }
@@ -289,6 +300,7 @@ int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux
     P.H = Huu; P.Hux = Hux; P.Hxx = Hxx; P.fu = fu; P.fx = fx; P.gs = nullptr; P.g_host = g;
     P.A = Au; P.Ax = Ax; P.b = b; P.ws = ws; P.ws_status = ws_status;
     const PrepGeom G = prep_geom(n, m, p);
+    if (int rc = check_prep(G, n, m, p)) return rc;
     P.tile_rows = G.tile_rows;
     if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
     hipLaunchKernelGGL(qp_prepare_kernel, dim3(1), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, P);
@@ -473,6 +485,7 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
     Q.g_host = 0.0;
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
     const PrepGeom G = prep_geom(n, m, Q.p, B);
+    if (int rc = check_prep(G, n, m, Q.p)) return rc;
     Q.tile_rows = G.tile_rows;
     if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
     hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);
@@ -487,7 +500,8 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
 
 size_t pympc_mpqp_multi_workspace_doubles(int n, int m, int p, int64_t B)
 {
-    if (n < 1 || m < 1 || p < 0 || n > kNMax || m > kMMax || B < 0) return 0;
+    if (n < 1 || m < 1 || p < 0 || n > kNMax || m > kMMax || p > kPMax || B < 0) return 0;
+    if (prep_geom(n, m, p, B).lds_bytes > kLdsBytes) return 0;
     return ws_layout(n, m, p).total * (size_t)B + ((size_t)B + 1) / 2 + 32;
 }
 
@@ -519,6 +533,7 @@ int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, co
     Q.b = b; Q.b_stride = m;
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
     const PrepGeom G = prep_geom(n, m, Q.p, B);
+    if (int rc = check_prep(G, n, m, Q.p)) return rc;
     Q.tile_rows = G.tile_rows;
     if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
     hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);

@@ -30,6 +30,7 @@ constexpr int kStatusNotPD = 4;
 constexpr int kStatusPending = -1;   // between the screening pass and the solve kernel only: never returned
 
 constexpr int kNMax = 63;    // variables: R = n + 1 <= 64 rows, one lane per row
+constexpr int kPMax = 64;    // parameters: the parameter vector is staged one entry per lane
 constexpr int kMTMax = 32;   // columns per lane
 constexpr int kMMax = 64 * kMTMax;
 

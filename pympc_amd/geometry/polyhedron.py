@@ -278,7 +278,13 @@ class Polyhedron(object):
 
     @property
     def bounded(self):
-        """Stiemke's alternative: bounded iff ker(A) = 0 and some y >= 1 has A'y = 0 (polyhedron.py:528-576)."""
+        """
+        Bounded iff ker(A) = 0 and the polyhedron has no recession direction (polyhedron.py:528-576).  The reference
+        decides the second part with Stiemke's alternative, an LP with one variable per ROW of A (some y >= 1 with
+        A'y = 0); that LP is used here while it fits the LP kernel (rows <= 32 variables).  Beyond that the same decision
+        is taken in the primal space: a non-empty polyhedron is bounded iff the 2 dim LPs max +-x_i over it all have an
+        optimum (one batched launch against the shared constraint matrix).
+        """
         if self._bounded is not None:
             return self._bounded
         if self.empty:
@@ -287,8 +293,22 @@ class Polyhedron(object):
         if nullspace_basis(A).shape[1] > 0:
             return False
         n, m = A.shape
-        sol = linear_program(np.ones(n), -np.eye(n), -np.ones(n), A.T, np.zeros(m))
-        self._bounded = sol['min'] is not None
+        from .. import _hip
+        n_lp_max = _hip.lp_limits()[0]
+        if n <= n_lp_max:
+            sol = linear_program(np.ones(n), -np.eye(n), -np.ones(n), A.T, np.zeros(m))
+            self._bounded = sol['min'] is not None
+        elif m <= n_lp_max:
+            b = np.concatenate((self.b, self.d, -self.d))
+            F = np.vstack((np.eye(m), -np.eye(m)))
+            res = hip_lp.linear_program_batch(F, A, b, want_argmin=False, want_mult=False, want_active=False)
+            st = res.numpy('status')
+            if np.any(st == 3):
+                raise RuntimeError('Maximum number of iterations reached.')
+            self._bounded = bool(np.all(st == 0))   # (non-empty: a failed LP is an unbounded direction)
+        else:
+            raise NotImplementedError('bounded: %d rows and %d variables are both beyond the LP kernel (%d variables)'
+                                      % (n, m, n_lp_max))
         return self._bounded
 
     def contains(self, x, tol=1.e-7):
@@ -309,20 +329,28 @@ class Polyhedron(object):
         import torch
         from .. import _hip
         lib = _hip.load_library()
-        if self.C.shape[0] > 0:
-            raise NotImplementedError('batched contains with equalities')
         X = _hip.to_device(X)
         B, p = X.shape
-        m = self.A.shape[0]
-        A = _hip.to_device(self.A); b = _hip.to_device(self.b)
-        row_ptr = _hip.to_device(np.array([0, m], np.int32), dtype=torch.int32)
-        z = torch.zeros(max(p * p, 1), dtype=torch.float64, device=X.device)
-        idx = torch.empty(B, dtype=torch.int32, device=X.device)
-        V = torch.empty(B, dtype=torch.float64, device=X.device)
-        _hip.check(lib.pympc_point_location(1, m, p, 0, _hip.ptr(A), _hip.ptr(b), _hip.ptr(row_ptr), None, None,
-                                            _hip.ptr(z), _hip.ptr(z), _hip.ptr(z), None, None, 0, None, _hip.ptr(X), B, float(tol),
-                                            _hip.ptr(idx), None, _hip.ptr(V), _hip.stream_ptr()))
-        return (idx == 0).cpu().numpy()
+
+        def inside(A, b, t):
+            """max(A x - b) <= t for every row x of X: the point-location kernel with one region."""
+            m = A.shape[0]
+            Ad = _hip.to_device(A); bd = _hip.to_device(b)
+            row_ptr = _hip.to_device(np.array([0, m], np.int32), dtype=torch.int32)
+            z = torch.zeros(max(p * p, 1), dtype=torch.float64, device=X.device)
+            idx = torch.empty(B, dtype=torch.int32, device=X.device)
+            V = torch.empty(B, dtype=torch.float64, device=X.device)
+            _hip.check(lib.pympc_point_location(1, m, p, 0, _hip.ptr(Ad), _hip.ptr(bd), _hip.ptr(row_ptr), None, None,
+                                                _hip.ptr(z), _hip.ptr(z), _hip.ptr(z), None, None, 0, None, _hip.ptr(X), B,
+                                                float(t), _hip.ptr(idx), None, _hip.ptr(V), _hip.stream_ptr()))
+            return idx == 0
+
+        if self.C.shape[0] == 0:
+            return inside(self.A, self.b, tol).cpu().numpy()
+        # the reference's equality test is |max(C x - d)| <= tol (polyhedron.py:598-602): max <= tol, and not max < -tol
+        upper = inside(np.vstack((self.A, self.C)), np.concatenate((self.b, self.d)), tol)
+        below = inside(self.C, self.d, np.nextafter(-tol, -np.inf))
+        return (upper & ~below).cpu().numpy()
 
     def is_included_in(self, P2, tol=1.e-7):
         """P subset of P2?  One LP per facet of P2 (polyhedron.py:606-641), issued as one batch."""
@@ -337,8 +365,9 @@ class Polyhedron(object):
         if np.any(st == 3):
             raise RuntimeError('Maximum number of iterations reached.')
         if np.any(st != 0):
-            # the reference evaluates -None here (TypeError); an unbounded direction certainly leaves P2
-            return False
+            # an LP without optimum (P unbounded along a facet normal of P2, or P empty): the reference evaluates
+            # -sol['min'] with sol['min'] None at polyhedron.py:636 and raises TypeError; same error here
+            raise TypeError("bad operand type for unary -: 'NoneType' (a facet LP of is_included_in has no optimum)")
         penetration = - res.numpy('min') - b2
         return bool(not np.any(penetration > tol))
 

@@ -26,11 +26,18 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load_library()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.pympc_hip_abi_version() >= 5   # 5: the prepared mpQP workspace carries the Gram matrix
+    assert lib.pympc_hip_abi_version() >= 6   # 6: raw NNLS / PNNLS and the static-scratch mpQP entry points
     nmax, mmax = _hip.limits()
     assert nmax >= 20 and mmax >= 370
     assert lib.pympc_mpqp_workspace_doubles(20, 370, 4) > 20 * 370 + 384 * 384   # 370 rows padded to 384 columns
     assert lib.pympc_mpqp_workspace_doubles(1000, 370, 4) == 0
+    # shapes inside the variable / row limits whose parameter count does not fit: refused, never a raw launch error
+    assert lib.pympc_mpqp_workspace_doubles(20, 370, 65) == 0          # the parameter vector is staged one entry per lane
+    assert lib.pympc_mpqp_workspace_doubles(63, 100, 4) > 0
+    assert lib.pympc_mpqp_workspace_doubles(63, 100, 8) == 0           # factor matrices + Hux beyond 160 KiB of LDS
+    assert lib.pympc_mpqp_multi_workspace_doubles(63, 100, 8, 10) == 0
+    assert lib.pympc_nnls_workspace_doubles(64, 2048, 3) > 0 and lib.pympc_nnls_workspace_doubles(65, 10, 3) == 0
+    assert lib.pympc_pnnls_workspace_doubles(64, 100, 64, 2) > 0 and lib.pympc_pnnls_workspace_doubles(64, 100, 65, 2) == 0
 
 
 def test_no_gpu_means_loud_failure():

@@ -1,6 +1,8 @@
 """The reference's Polyhedron known-answer tests for the methods on the hot path
 (pympc/test/test_geometry/test_polyhedron.py:301-393, 449-470, 472-520, 581-632), run against
 pympc_amd.geometry.polyhedron on the GPU.  Inputs and expected values are the data those tests hold."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,51 @@ def test_chebyshev():
     assert abs(p.radius - np.sqrt(2.)) < 1e-7
     assert abs(p.center[0]) < 1e-7 and abs(p.center[2]) < 1e-7
     assert np.abs(p.center[1]) < 2. - p.radius + 1.e-6
+
+
+def test_bounded_with_more_rows_than_the_stiemke_lp_holds():
+    """polyhedron.py:528-576 has no size limit; beyond 32 rows the decision is taken in the primal space."""
+    Polyhedron = _P()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_model.npz"))
+    XN = Polyhedron(g["XN_A"], g["XN_b"])                               # the 130-facet cart-pole terminal set (mcais)
+    assert XN.A.shape[0] == 130 and XN.bounded
+    rng = np.random.RandomState(4)
+    A = rng.randn(60, 5); A /= np.linalg.norm(A, axis=1)[:, None]
+    assert Polyhedron(A, np.ones(60)).bounded                           # 60 random facets around the origin
+    A[:, 0] = -np.abs(A[:, 0])                                          # every normal has a non-positive first entry:
+    assert not Polyhedron(A, np.ones(60)).bounded                       # +e_0 is a recession direction
+    p = Polyhedron.from_bounds(-np.ones(3), np.ones(3))
+    for k in range(40):
+        p.add_inequality(rng.randn(1, 3), np.array([5.]))
+    assert p.bounded
+
+
+def test_contains_batch_with_equalities():
+    """The batched form of polyhedron.py:578-604 with equalities: same decisions as the scalar form, row by row
+    (including the reference's |max(C x - d)| <= tol, which only looks at the largest entry)."""
+    Polyhedron = _P()
+    p = Polyhedron.from_bounds(1. * np.ones(2), 3. * np.ones(2))
+    p.add_equality(np.ones((1, 2)), np.array([4.]))
+    X = np.array([[2., 2.], [2.5, 2.5], [3.5, 3.5], [1., 3.], [3., 1. + 5e-8], [3., 1. + 2e-7], [2., 2. - 5e-8], [2., 2. - 2e-7],
+                  [0.5, 3.5]])
+    got = p.contains(X)
+    assert list(got) == [bool(p.contains(x)) for x in X]
+    assert list(got) == [True, False, False, True, True, False, True, False, False]
+    p = Polyhedron.from_bounds(-np.ones(3), np.ones(3))
+    p.add_equality(np.array([[1., 1., 0.], [0., 1., -1.]]), np.array([0., .5]))
+    rng = np.random.RandomState(0)
+    X = rng.uniform(-1.2, 1.2, (2000, 3))
+    X[::2, 0] = -X[::2, 1]; X[::2, 2] = X[::2, 1] - .5                  # half of the points on the equalities
+    X[::4, 2] -= 1e-3                                                   # second residual negative, first zero: still "inside"
+    got = p.contains(X)
+    assert list(got) == [bool(p.contains(x)) for x in X] and got.sum() > 100
+
+
+def test_errors_where_the_reference_fails():
+    """is_included_in with an LP without optimum: the reference raises TypeError (-None, polyhedron.py:636)."""
+    Polyhedron = _P()
+    half = Polyhedron.from_lower_bound(np.zeros(2))                     # unbounded
+    box = Polyhedron.from_bounds(-np.ones(2), np.ones(2))
+    assert box.is_included_in(Polyhedron.from_bounds(-2. * np.ones(2), 2. * np.ones(2)))
+    with pytest.raises(TypeError):
+        half.is_included_in(box)

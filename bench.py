@@ -80,6 +80,22 @@ def cpu_baseline(model, x_max, scale, seconds_target=12.0):
     return out
 
 
+def reference_python_rate(scale):
+    """SURVEY 8(d) 'reference-as-is' figure: the reference's own ModelPredictiveController path (CPython + scipy 1.15.3
+    nnls, 1 core) timed in the build container while tests/golden/make_golden.py::gen_c2big solved the first 10 000
+    states of this benchmark's stream; the reference's files do not travel to the GPU box, so the recorded time is
+    read back from the fixture."""
+    tag = {0.3: "s03", 1.0: "s10"}.get(round(scale, 1))
+    path = os.path.join(ROOT, "tests", "golden", "c2_big_%s.npz" % tag) if tag else None
+    if not path or not os.path.exists(path):
+        return None
+    rec = np.load(path)
+    n = int(rec["X"].shape[0])
+    return dict(value=n / float(rec["ref_seconds"]), unit="QP solves/s", cores=1, kind="reference",
+                sample="%d states (the first of this benchmark's stream, s=%.1f) through the reference's mpqp.solve" % (n, scale),
+                where="build container (8 vCPU, no GPU), CPython 3.10 + numpy 2.2 + scipy 1.15.3; recorded in " + os.path.basename(path))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +109,10 @@ def main():
     ap.add_argument("--compare-plain", action="store_true",
                     help="also time the same launch without certificates (extra launches: keep it off under a profiler)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the all-gather of (u0, status) even with one rank")
+    ap.add_argument("--pcie-chunks", type=int, default=1,
+                    help="0: skip the PCIe-inclusive (host-to-host) measurement")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -107,8 +127,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pympc_amd.optimization.solvers.hip import PreparedMpqp, _alloc_outputs
@@ -122,7 +144,7 @@ def main():
     B = args.batch
     X = torch.as_tensor(np.random.RandomState(rank).uniform(-args.scale * x_max, args.scale * x_max, (B, p))).to(dev)
     out = _alloc_outputs(B, nu, m, dev, want_mult=False, want_active=True, want_iters=False)
-    gather = world > 1 and not args.no_gather
+    gather = use_dist and not args.no_gather
     if gather:
         g_u = torch.empty((world * B, nu), dtype=torch.float64, device=dev)
         g_s = torch.empty(world * B, dtype=torch.int32, device=dev)
@@ -141,7 +163,7 @@ def main():
             dist.all_gather_into_tensor(g_s, out["status"])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,10 +182,65 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- PCIe-inclusive figure (wall time incl. H2D of the states and D2H of the results; reported next
+    # to `value`, which by the bench contract counts states resident in HBM).  Every step uploads its 1M states from
+    # pinned host memory and downloads (u0, status) to pinned host memory.  Two sets of device buffers: the upload of
+    # step t + 1 and the download of step t - 1 overlap the solve of step t (three streams).  Splitting ONE step into
+    # chunks instead was measured and is slower (3.2 / 4.2 / 5.5 / 7.2 ms per step with 1 / 2 / 4 / 8 chunks: the solve
+    # kernel's tail and the learning pre-pass are paid per launch).
+    pcie = None
+    if args.pcie_chunks > 0 and rank == 0:
+        nbuf = 2
+        Xh = X.cpu().pin_memory()
+        uh = [torch.empty((B, nu), dtype=torch.float64).pin_memory() for _ in range(nbuf)]
+        sh = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
+        Xd = [torch.empty_like(X) for _ in range(nbuf)]
+        outs = [out] + [_alloc_outputs(B, nu, m, dev, want_mult=False, want_active=True, want_iters=False) for _ in range(nbuf - 1)]
+        comp = torch.cuda.current_stream()
+        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+        ev_in = [torch.cuda.Event() for _ in range(nbuf)]
+        ev_done = [torch.cuda.Event() for _ in range(nbuf)]
+        ev_out = [torch.cuda.Event() for _ in range(nbuf)]
+
+        def host_step(t):
+            k = t % nbuf
+            s_in.wait_event(ev_done[k])              # the solve that last read this buffer's states has finished
+            with torch.cuda.stream(s_in):
+                Xd[k].copy_(Xh, non_blocking=True)
+                ev_in[k].record(s_in)
+            comp.wait_event(ev_in[k])
+            comp.wait_event(ev_out[k])               # ... and this buffer's previous results have left the device
+            if args.cuts == "cold":
+                prep.reset_cuts()
+            prep.solve_batch(Xd[k], n_out=nu, out=outs[k], use_cuts=use_cuts)
+            ev_done[k].record(comp)
+            s_out.wait_event(ev_done[k])
+            with torch.cuda.stream(s_out):
+                uh[k].copy_(outs[k]["argmin"], non_blocking=True)
+                sh[k].copy_(outs[k]["status"], non_blocking=True)
+                ev_out[k].record(s_out)
+
+        for k in range(nbuf):
+            ev_done[k].record(comp)
+            ev_out[k].record(comp)
+        for t in range(max(2, args.warmup)):
+            host_step(t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(args.steps):
+            host_step(t)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        assert int((sh[0] == 0).sum()) == int((out["status"] == 0).sum())
+        pcie = {"value": B * args.steps / dt, "unit": "QP solves/s", "ms_per_step": dt / max(args.steps, 1) * 1e3,
+                "device_buffer_sets": nbuf, "host_bytes_per_state": 8 * p + 8 * nu + 4,
+                "note": "every step: pinned host states in, (u0, status) out to pinned host memory, certificate table "
+                        "emptied before the step's solve; transfers of neighbouring steps overlap the solve; one GPU (rank 0)"}
 
     # roofline accounting: one extra untimed pass that also writes the iteration counters (deterministic kernel)
     if args.cuts == "cold":
@@ -231,11 +308,14 @@ def main():
                                  "TFLOP/s on this part: benchmarks/fp64_rate.hip, profiles/r01_v5/fp64_rate.txt)",
                          "measured_fp64_fma_tflops": 53.2},
         }
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(model, x_max, args.scale)
+            line["cpu_baseline"]["reference_python"] = reference_python_rate(args.scale)
             line["gpu_over_cpu_1core"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -37,10 +37,11 @@ def gather_rows(local, B):
     """All-gather of per-problem rows: every rank passes its shard [hi - lo x ...] and receives [B x ...] in global
     order.  Shards are padded to the largest one so that a single fixed-size all_gather_into_tensor does the job."""
     rank, world = _world()
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         if local.shape[0] != B:
             raise ValueError('local shard has %d rows, expected %d' % (local.shape[0], B))
         return local
+    # (an initialised group of ONE rank still goes through the collective: the same code path as N ranks)
     lo, hi = shard_range(B, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError('rank %d: local shard has %d rows, expected %d' % (rank, local.shape[0], hi - lo))

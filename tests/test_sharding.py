@@ -75,3 +75,39 @@ def test_sharded_feedback_gloo(tmp_path, oracle, world, B):
         assert np.array_equal(got["u0"][feas], ref["argmin"][feas][:, :1])       # same code on the same rows: bit-exact
         assert int(got["k"]) == int(np.argmin(V)) and float(got["v"]) == float(V.min())
         assert np.array_equal(got["tags"], np.repeat(owner[:, None], 3, axis=1))
+
+
+@pytest.mark.gpu
+def test_sharded_feedback_hip_solver_through_rccl_one_rank():
+    """solve_sharded with the HIP local solver under torch.distributed "nccl" (= RCCL) with ONE rank on the GPU box: the
+    code path of N ranks (init_process_group, shard_range, all_gather_into_tensor on device tensors), checked against
+    the plain batched call.  N > 1 launch lines: README.md."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from pympc_amd import sharding
+from pympc_amd.optimization.solvers.hip import PreparedMpqp
+m = dict(np.load(os.path.join(%r, "tests", "golden", "c1_model.npz")))
+prep = PreparedMpqp(m["Huu"], m["Hux"], m["Hxx"], m["fu"], m["fx"], float(m["g"]), m["Au"], m["Ax"], m["b"])
+X = torch.as_tensor(np.random.RandomState(0).uniform([-5., -1.], [5., 1.], (1001, 2))).cuda()
+def local(Xs):
+    r = prep.solve_batch(Xs, n_out=1, want_mult=False, want_active=False)
+    return dict(u0=r.t["argmin"], status=r.t["status"], V=r.t["min"])
+got, _ = sharding.solve_sharded(local, X, ("u0", "status", "V"))
+ref = local(X)
+torch.cuda.synchronize()
+assert torch.equal(got["status"], ref["status"])
+assert torch.equal(torch.nan_to_num(got["u0"]), torch.nan_to_num(ref["u0"]))
+cost = torch.where(ref["status"] == 0, ref["V"], torch.full_like(ref["V"], float("inf")))
+k, v = sharding.argmin_over_ranks(cost, X.shape[0])
+assert k == int(torch.argmin(cost)) and v == float(cost.min())
+dist.barrier(); dist.destroy_process_group()
+print("sharded ok", int((ref["status"] == 0).sum()))
+''' % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0 and "sharded ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -145,3 +145,37 @@ def pnnls(A, B, c):
     if int(st.item()) == _hip.MAXITER:
         raise RuntimeError('Maximum number of iterations reached.')
     return v[0].cpu().numpy(), u[0].cpu().numpy(), float(rn.item())
+
+
+def linear_program_pnnls(f, A, b, C=None, d=None, tol=TOL):
+    """The reference's own LP formulation on the device, for small LPs (1 + m + n <= 64 rows after folding equalities):
+    the KKT system of pnnls.py:109-124 solved by pnnls(), solvable iff the residual is below tol (pnnls.py:137).
+    linear_program() reaches the same primal-dual pair with a dual active-set method in n-space and decides
+    feasibility row by row (violation above 1e-9 max(1, |b_j|)); the two decisions differ only for LPs that are
+    infeasible or unbounded by a margin between those tolerances -- this form reproduces the reference's decision there."""
+    if (C is None) != (d is None):
+        raise ValueError('missing C or d.')
+    f = np.asarray(f, dtype=np.float64)
+    A = np.asarray(A, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    n_ineq, n_x = A.shape
+    n_eq = 0 if C is None else np.asarray(C).shape[0]
+    if n_eq > 0:
+        C = np.asarray(C, dtype=np.float64); d = np.asarray(d, dtype=np.float64)
+        AC = np.vstack((A, C, -C)); bd = np.concatenate((b, d, -d))
+    else:
+        AC, bd = A, b
+    m = AC.shape[0]
+    A_p = np.vstack((np.concatenate((bd, np.zeros(m))), np.hstack((np.zeros((m, m)), np.eye(m))),
+                     np.hstack((AC.T, np.zeros((n_x, m))))))
+    B_p = np.vstack((f, AC, np.zeros((n_x, n_x))))
+    c_p = np.concatenate((np.zeros(1), bd, -f))
+    ys, x, r = pnnls(A_p, B_p, c_p)
+    sol = {'min': None, 'argmin': None, 'active_set': None, 'multiplier_inequality': None, 'multiplier_equality': None}
+    if r < tol:
+        sol['argmin'] = x
+        sol['min'] = float(f.dot(x))
+        sol['multiplier_inequality'] = ys[:n_ineq]
+        sol['active_set'] = sorted(int(i) for i in np.where(sol['multiplier_inequality'] > tol)[0])
+        if n_eq > 0:
+            sol['multiplier_equality'] = ys[n_ineq:n_ineq + n_eq] - ys[n_ineq + n_eq:m]
+    return sol

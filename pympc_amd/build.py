@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
-LIB_PATH = os.path.join(LIB_DIR, "libpympc_hip.so")
+LIB_PATH = os.environ.get("PYMPC_HIP_LIB") or os.path.join(LIB_DIR, "libpympc_hip.so")   # (override: debug builds)
 SOURCES = ["pympc_hip.hip"]
 HEADERS = ["ws_layout.hpp", "qp_wave.hpp", "qp_screen.hpp", "nnls_raw.hpp", "qp_prepare.hpp", "point_location.hpp", "lp_block.hpp", "lp_tile.hpp", "invqr_wave.hpp", "condense.hpp",
            os.path.join("..", "..", "include", "pympc_hip.h")]
@@ -44,6 +44,22 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+PROBE_PATH = os.path.join(LIB_DIR, "libpympc_probe.so")
+
+
+def build_probes(force=False):
+    """Small stand-alone probes (csrc/probes/*.hip) in one library: hardware / compiler facts the kernels rely on."""
+    src = os.path.join(CSRC, "probes", "mfma_f64_hazard.hip")
+    if not force and os.path.exists(PROBE_PATH) and os.path.getmtime(PROBE_PATH) >= os.path.getmtime(src):
+        return PROBE_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+                           "-o", PROBE_PATH, src])
+    return PROBE_PATH
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    build_probes(force="--force" in sys.argv)
     print(LIB_PATH)

@@ -53,13 +53,21 @@ __device__ __forceinline__ cond_d4 mfma_f64(double a, double b, cond_d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// hipcc 7.2 pads a v_mfma_f64_16x16x4_f64 result with 19 wait states before its first non-MFMA reader.  On gfx950
-// (fp64 MFMA at half of gfx942's rate) that was measured to be too few: register 3 of the accumulator (rows 12-15,
-// written by the last pass) still held its previous value.  Every chain therefore ends with explicit wait states
-// tied to the accumulator before anything reads it.
+// End of an MFMA chain: the accumulator is pinned to AGPRs and every later reader is ordered behind this point.
+// Round 1 had four `s_nop 15` here on the belief that hipcc 7.2's wait states between a v_mfma_f64_16x16x4_f64 and
+// its first non-MFMA reader were too few on gfx950.  The isolated probe (csrc/probes/mfma_f64_hazard.hip,
+// benchmarks/mfma_hazard.py, profiles/r02/mfma_hazard.jsonl) shows the compiler's own wait states are sufficient:
+// 3 x 4096 chains read back exactly with no pad.  What this kernel needs is the constraint itself: built with the
+// empty statement below all parity tests pass, built without any statement three of them fail (accumulator register 3
+// stale; -DPYMPC_NO_MFMA_SETTLE reproduces it).  So: no wait states (they cost ~9 k cycles per mode sequence), the
+// constraint stays, and tests/test_gpu_condense.py::test_mfma_f64_needs_no_wait_state_pad pins both findings.
 __device__ __forceinline__ void mfma_f64_settle(cond_d4 &acc)
 {
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(acc));
+#ifndef PYMPC_NO_MFMA_SETTLE
+    asm volatile("" : "+a"(acc));
+#else
+    (void)acc;
+#endif
 }
 
 __device__ __forceinline__ void cond_lds_sync()

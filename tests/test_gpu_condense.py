@@ -206,3 +206,20 @@ def test_hybrid_bigM_vs_reference_golden():
     ctrl_bad = HybridModelPredictiveController(bad, 3, np.eye(4), np.eye(1), np.eye(4), domains[1])
     with pytest.raises(ValueError):
         ctrl_bad._get_bigM_domains()
+
+
+def test_mfma_f64_needs_no_wait_state_pad():
+    """csrc/probes/mfma_f64_hazard.hip: chains of v_mfma_f64_16x16x4_f64 whose accumulator is stored immediately, with and
+    without explicit wait states.  Both variants must be exact: the condensing kernel relies on the compiler's own
+    hazard handling (it only pins the accumulator, csrc/condense.hpp::mfma_f64_settle).  If the unpadded variant ever
+    returns a wrong entry, the wait states have to come back."""
+    import ctypes
+    from pympc_amd.build import PROBE_PATH
+    lib = ctypes.CDLL(PROBE_PATH)
+    lib.pympc_probe_mfma_f64.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong),
+                                         ctypes.POINTER(ctypes.c_int)]
+    for ks in (1, 2, 4):
+        for pad in (1, 0):
+            wrong = ctypes.c_longlong(-1); mask = ctypes.c_int(0)
+            assert lib.pympc_probe_mfma_f64(pad, ks, 2048, ctypes.byref(wrong), ctypes.byref(mask)) == 0
+            assert wrong.value == 0, "k_steps %d pad %d: %d wrong entries, accumulator registers %#x" % (ks, pad, wrong.value, mask.value)

@@ -8,6 +8,8 @@
         get_mpqp(mode_sequence)                                 :668-680
         _get_bigM_dynamics() / _get_bigM_domains()              :289-405   one batched LP launch per domain
         get_mpqp_batch(mode_sequences) / solve_mode_sequences(x, mode_sequences)      (batched, new)
+        feedforward(x) / feedback(x)                            :611-666   exact pruned enumeration of the mode sequences
+                                                                           in place of the Gurobi MIQP
     condense_optimal_control_problem(S, Q, R, P, X_N, mode_sequence)                :682-749
 
 The mixed-integer program itself (mpMIQP condensing and its solution through Gurobi, :407-666) is outside the pnnls path.
@@ -126,6 +128,7 @@ class HybridModelPredictiveController(object):
         self.P = P
         self.X_N = X_N
         self._tables = None
+        self._ptables = None
 
     def tables(self):
         if self._tables is None:
@@ -199,6 +202,88 @@ class HybridModelPredictiveController(object):
         """get_mpqp(ms).solve(x) for every row ms of mode_sequences; returns (BatchResult, MpqpBatch)."""
         batch = self.get_mpqp_batch(mode_sequences)
         return batch.solve(x, **kwargs), batch
+
+    # ------------------------------------------------------------------ mode-sequence search (in place of the MIQP)
+    def _prefix_tables(self):
+        """Tables of the prefix relaxation: horizon t < N with the mode sequence's first t modes, terminal weight Q and no
+        terminal set.  Its optimal value is a lower bound for every completion of the prefix (the completion keeps all of
+        the prefix's constraints and costs, x_t is weighted with Q there as well, everything added is non-negative)."""
+        if getattr(self, '_ptables', None) is None:
+            from ..geometry.polyhedron import Polyhedron
+            free = Polyhedron(np.zeros((0, self.S.nx)), np.zeros(0))
+            self._ptables = PwaTables(self.S.affine_systems, self.S.domains, self.Q, self.R, self.Q, free)
+        return self._ptables
+
+    def _evaluate(self, x, seqs):
+        """Optimal values (inf where infeasible) and solutions of the fixed-mode-sequence QPs of seqs [B x t]: prefix
+        relaxations for t < N, the full problem (terminal cost P, terminal set X_N) for t = N."""
+        t = seqs.shape[1]
+        batch = condense_batch(self.tables() if t == self.N else self._prefix_tables(), seqs)
+        res = batch.solve(x, want_mult=False, want_active=False)
+        V = torch.where(res.t['status'] == 0, res.t['min'], torch.full_like(res.t['min'], float('inf')))
+        return V.cpu().numpy(), res
+
+    def feedforward(self, x, verbose=False):
+        """
+        Optimal input sequence, state trajectory, mode sequence and cost for the state x, or (None, None, None, None)
+        when no mode sequence is feasible -- the return values of controllers.py:611-648, which the reference obtains
+        from a mixed-integer QP (Gurobi).  Here: exact enumeration of the mode sequences with pruning, every level of
+        the tree one batched launch (condensing kernel + QP kernel) over the surviving prefixes x modes:
+          * a prefix whose relaxation (see _prefix_tables) is infeasible has no feasible completion;
+          * a prefix whose relaxation already costs more than the best complete sequence found so far cannot improve it
+            (the incumbent comes from one greedy dive before the sweep).
+        """
+        nm, N, nu = self.S.nm, self.N, self.S.nu
+        x = np.asarray(x, dtype=np.float64)
+        best_V, best_seq, best_u = float('inf'), None, None
+
+        def children(front):
+            return np.hstack((np.repeat(front, nm, axis=0), np.tile(np.arange(nm, dtype=np.int32), front.shape[0])[:, None]))
+
+        def complete(V, res, seqs):
+            nonlocal best_V, best_seq, best_u
+            k = int(np.argmin(V))
+            if V[k] < best_V:
+                best_V, best_seq, best_u = float(V[k]), seqs[k].copy(), res.t['argmin'][k].cpu().numpy()
+
+        # greedy dive: follow the cheapest feasible child
+        front = np.zeros((1, 0), dtype=np.int32)
+        for t in range(1, N + 1):
+            seqs = children(front)
+            V, res = self._evaluate(x, seqs)
+            if not np.isfinite(V).any():
+                break
+            if t == N:
+                complete(V, res, seqs)
+            front = seqs[[int(np.argmin(V))]]
+        # level-by-level sweep with pruning
+        front = np.zeros((1, 0), dtype=np.int32)
+        for t in range(1, N + 1):
+            seqs = children(front)
+            V, res = self._evaluate(x, seqs)
+            if t == N:
+                if np.isfinite(V).any():
+                    complete(V, res, seqs)
+                break
+            keep = np.isfinite(V) & (V <= best_V + 1e-9 * max(1., abs(best_V) if np.isfinite(best_V) else 1.))
+            if verbose:
+                print('level %d: %d prefixes, %d survive (incumbent %g)' % (t, seqs.shape[0], int(keep.sum()), best_V))
+            front = seqs[keep]
+            if front.shape[0] == 0:
+                break
+        if best_seq is None:
+            return None, None, None, None
+        u_list = [best_u[nu * t:nu * (t + 1)] for t in range(N)]
+        x_list = [x]
+        for t in range(N):
+            Sz = self.S.affine_systems[int(best_seq[t])]
+            x_list.append(Sz.A.dot(x_list[-1]) + Sz.B.dot(u_list[t]) + getattr(Sz, 'c', np.zeros(self.S.nx)))
+        return u_list, x_list, [int(z) for z in best_seq], best_V
+
+    def feedback(self, x):
+        """First input of feedforward(x), or None (controllers.py:650-666)."""
+        u = self.feedforward(x)[0]
+        return None if u is None else u[0]
 
     def feedforward_over(self, x, mode_sequences):
         """

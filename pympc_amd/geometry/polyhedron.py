@@ -14,7 +14,11 @@ Same names, arguments and error behaviour as the reference for
     is_included_in(P2, tol)                                  :606-641     one LP per facet of P2 -> batched
     intersection / cartesian_product                         :643-685
     radius / center / _chebyshev()                           :687-768     one LP
-Vertex enumeration, projection and plotting (qhull / matplotlib glue) are outside the hot path.
+    vertices                                                 :770-824     qhull on the host (HalfspaceIntersection)
+    from_convex_hull(points)                                 :856-877     qhull on the host
+    project_to(residual_dimensions)                          :826-854     convex-hull method, its LPs batched
+                                                                          (geometry/orthogonal_projection.py)
+Plotting (matplotlib glue) is outside the hot path.
 """
 from copy import copy
 
@@ -404,3 +408,63 @@ class Polyhedron(object):
                 r = np.linalg.inv(self.C.dot(R)).dot(self.d)
                 center = np.hstack((N, R)).dot(np.concatenate((center, r)))
         return radius, center
+
+    # ------------------------------------------------------------------ vertices / convex hull / projection
+    @property
+    def vertices(self):
+        """
+        Vertices of a bounded, full-dimensional polytope as a list of arrays, None if unbounded or (nearly) flat
+        (polyhedron.py:770-824): boundedness and the Chebyshev centre come from the LP kernel, the enumeration itself is
+        qhull's half-space intersection on the host, as in the reference.
+        """
+        if self._vertices is not None:
+            return self._vertices
+        if not self.bounded:
+            return None
+        if self.radius < 1.e-7:
+            return None
+        from scipy.spatial import HalfspaceIntersection
+        if self.C.shape[0] > 0:
+            A, b, N, R = self._remove_equalities()
+            T = np.hstack((N, R))
+            center = np.linalg.inv(T).dot(self.center)[:N.shape[1]]
+        else:
+            A, b, center = self.A, self.b, self.center
+        if A.shape[1] == 1:
+            p = Polyhedron(A.copy(), b.copy())
+            p.remove_redundant_inequalities()
+            verts = [np.array([p.b[i] / p.A[i, 0]]) for i in (0, 1)]
+        else:
+            V = HalfspaceIntersection(np.column_stack((A, -b)), center).intersections
+            verts = [V[i] for i in range(V.shape[0])]
+        if self.C.shape[0] > 0:
+            r = np.linalg.inv(self.C.dot(R)).dot(self.d)
+            verts = [T.dot(np.concatenate((v, r))) for v in verts]
+        self._vertices = verts
+        return self._vertices
+
+    @staticmethod
+    def from_convex_hull(points):
+        """Polytope {x | A x <= b} spanned by the given points (polyhedron.py:856-877, qhull on the host)."""
+        from scipy.spatial import ConvexHull
+        hull = ConvexHull(np.vstack(points))
+        p = Polyhedron(hull.equations[:, :-1].copy(), -hull.equations[:, -1].copy())
+        p._vertices = [hull.points[i] for i in hull.vertices]
+        return p
+
+    def project_to(self, residual_dimensions):
+        """
+        Orthogonal projection onto the given coordinates (polyhedron.py:826-854): ValueError for empty, unbounded or
+        lower-dimensional polyhedra; the convex-hull method with one batched LP launch per round.
+        """
+        if self.empty:
+            raise ValueError('cannot project empty polyhedra.')
+        if not self.bounded:
+            raise ValueError('cannot project unbounded polyhedra.')
+        if self.C.shape[0] > 0:
+            raise ValueError('cannot project lower-dimensional polyhedra.')
+        from .orthogonal_projection import convex_hull_method
+        A, b, vertices = convex_hull_method(self.A, self.b, residual_dimensions)
+        proj = Polyhedron(A, b)
+        proj._vertices = [v for v in vertices]
+        return proj

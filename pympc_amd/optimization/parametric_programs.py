@@ -116,6 +116,13 @@ class MultiParametricQuadraticProgram(object):
             print('feasible sample with active set ' + str(sol['active_set']) + '.')
         return self.explicit_solve_given_active_set(sol['active_set'])
 
+    def get_feasible_set(self):
+        """Feasible set {x | exists u: Au u + Ax x <= b} of the mpQP as a Polyhedron (parametric_programs.py:243-260):
+        projection of the constraint set onto the parameters (convex-hull method, batched LPs)."""
+        from ..geometry.polyhedron import Polyhedron
+        C = Polyhedron(np.hstack((self.A['x'], self.A['u'])), self.b)
+        return C.project_to(range(self.A['x'].shape[1]))
+
     def explicit_solve(self, step_size=1.e-5, verbose=False):
         """
         Explicit solution by facet flipping (parametric_programs.py:181-241): start at the origin, and for every

@@ -449,6 +449,58 @@ def gen_scipynnls():
     np.savez_compressed(os.path.join(HERE, "scipy_nnls_tests.npz"), **out)
 
 
+def gen_proj():
+    """Orthogonal projections (polyhedron.py:826-854, 941-1132): the reference's convex-hull method on random polytopes
+    in the manner of test_polyhedron.py:845-899 (m = 10 facets, n = 3..5 -> n_proj = 2..n-1) and on larger ones.  Stored:
+    A, b, the residual dimensions, and the reference's projection as minimal half-spaces + vertices (qhull order is
+    not part of the contract: the test compares sets)."""
+    print("orthogonal projections (convex-hull method)")
+    from pympc.geometry.polyhedron import convex_hull_method
+    rng = np.random.RandomState(3)
+    out = {}
+    k = 0
+    for m, dims in ((10, (3, 4, 5)), (16, (4,))):
+        for n in dims:
+            for n_proj in range(2, n):
+                for rep in range(3):
+                    A = rng.randn(m, n); b = rng.rand(m)
+                    P = Polyhedron(A.copy(), b.copy())
+                    print("    m=%d n=%d n_proj=%d rep=%d" % (m, n, n_proj, rep), flush=True)
+                    try:
+                        (verts, ok1) = certified_call(lambda: P.vertices)
+                    except Exception as e:
+                        print("      vertices failed: %s" % type(e).__name__, flush=True)
+                        continue
+                    if verts is None:
+                        continue
+                    import signal
+
+                    def _alarm(*_):
+                        raise RuntimeError("timeout")
+                    signal.signal(signal.SIGALRM, _alarm)
+                    signal.alarm(20)          # (the reference's loop does not end on some instances under this scipy)
+                    try:
+                        (res, ok2) = certified_call(convex_hull_method, A.copy(), b.copy(), list(range(n_proj)))
+                    except Exception as e:
+                        print("      convex_hull_method failed: %s" % type(e).__name__, flush=True)
+                        res = None
+                    finally:
+                        signal.alarm(0)
+                    if res is None:
+                        print("    m=%d n=%d n_proj=%d rep=%d: reference did not finish" % (m, n, n_proj, rep))
+                        continue
+                    E, f, V = res
+                    Q = Polyhedron(E, f)
+                    (_, ok3) = certified_call(Q.remove_redundant_inequalities)
+                    out["A%d" % k] = A; out["b%d" % k] = b; out["n_proj%d" % k] = np.asarray(n_proj)
+                    out["E%d" % k] = Q.A; out["f%d" % k] = Q.b; out["V%d" % k] = np.asarray(V)
+                    out["ok%d" % k] = np.asarray(ok1 and ok2 and ok3)
+                    k += 1
+    out["count"] = np.asarray(k)
+    print("  %d projections, certified %d" % (k, sum(bool(out["ok%d" % i]) for i in range(k))))
+    np.savez_compressed(os.path.join(HERE, "projections.npz"), **out)
+
+
 def gen_hybrid():
     """Config C5 anchors: get_mpqp(mode_sequence).solve(x0) for a handful of mode sequences (N=10)."""
     print("hybrid cart-pole fixed-mode-sequence QPs (N=10)")
@@ -529,8 +581,8 @@ def gen_bigm():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="c1,c2,c2big,ctrl,nb,lp,nnls,scipynnls,hybrid,bigm")
+    ap.add_argument("--only", default="c1,c2,c2big,ctrl,nb,lp,nnls,scipynnls,proj,hybrid,bigm")
     only = ap.parse_args().only.split(",")
-    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("c2big", gen_c2big), ("ctrl", gen_ctrl), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("scipynnls", gen_scipynnls), ("hybrid", gen_hybrid), ("bigm", gen_bigm)):
+    for name, fn in (("c1", gen_c1), ("c2", gen_c2), ("c2big", gen_c2big), ("ctrl", gen_ctrl), ("nb", gen_nb), ("lp", gen_lp), ("nnls", gen_nnls), ("scipynnls", gen_scipynnls), ("proj", gen_proj), ("hybrid", gen_hybrid), ("bigm", gen_bigm)):
         if name in only:
             fn()

@@ -301,6 +301,42 @@ class HybridModelPredictiveController(object):
         return [u[t * nu:(t + 1) * nu] for t in range(self.N)], float(V[k].item()), [int(z) for z in batch.modes[k].cpu().numpy()]
 
 
+def graph_representation(S):
+    """Graphs {(x, u, x+) | F_i x + G_i u <= h_i, x+ = A_i x + B_i u + c_i} of the modes of the PWA system S as a list of
+    Polyhedron, the equality written as two inequalities (examples/pwa_from_urdf/utils.py:349-369)."""
+    from ..geometry.polyhedron import Polyhedron
+    P = []
+    for Si, Di in zip(S.affine_systems, S.domains):
+        nx = S.nx
+        Ai = np.vstack((np.hstack((Di.A, np.zeros((Di.A.shape[0], nx)))), np.hstack((Si.A, Si.B, -np.eye(nx))),
+                        np.hstack((-Si.A, -Si.B, np.eye(nx)))))
+        P.append(Polyhedron(Ai, np.concatenate((Di.b, -Si.c, Si.c))))
+    return P
+
+
+def big_m(P_list, tol=1.e-6):
+    """m[i][j][k] = max over P_j of A_i[k] x - b_i[k] for a list of polyhedra {x | A_i x <= b_i}, values below tol set to
+    zero (examples/pwa_from_urdf/utils.py:371-389: one LP per (i, j, k), solved one after the other there).  The LPs
+    over the same P_j share their constraint set: one batched launch per j with the rows of every P_i as objectives."""
+    from ..optimization.solvers import hip_lp
+    rows = np.vstack([P.A for P in P_list])
+    rhs = np.concatenate([P.b for P in P_list])
+    off = np.cumsum([0] + [P.A.shape[0] for P in P_list])
+    m = [[None] * len(P_list) for _ in P_list]
+    for j, Pj in enumerate(P_list):
+        res = hip_lp.linear_program_batch(-rows, Pj.A, Pj.b, want_argmin=False, want_mult=False, want_active=False)
+        st = res.numpy('status')
+        if np.any(st == 3):
+            raise RuntimeError('Maximum number of iterations reached.')
+        if np.any(st != 0):
+            raise TypeError("bad operand type for unary -: 'NoneType' (an LP of big_m over polyhedron %d has no optimum)" % j)
+        v = -res.numpy('min') - rhs
+        v[np.abs(v) < tol] = 0.
+        for i in range(len(P_list)):
+            m[i][j] = v[off[i]:off[i + 1]].copy()
+    return m
+
+
 def condense_optimal_control_problem(S, Q, R, P, X_N, mode_sequence, tables=None):
     """Condensed mpQP of the PWA optimal control problem for one mode sequence (:682-749), by the MFMA kernel."""
     if tables is None:

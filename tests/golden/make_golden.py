@@ -576,6 +576,30 @@ def gen_bigm():
         for j in range(s):
             out["alpha_%d_%d" % (i, j)] = alpha[i][j]; out["beta_%d_%d" % (i, j)] = beta[i][j]
             out["gamma_%d_%d" % (i, j)] = gamma[i][j]
+    # big-Ms over the GRAPHS of the dynamics (examples/pwa_from_urdf/utils.py:349-389: graph_representation + big_m; that
+    # module imports pydrake and cannot be loaded, its big_m is a loop of the reference's linear_program over the rows
+    # below -- the same calls are issued here through the reference's LP path and certified against HiGHS)
+    graphs = []
+    for Si, Di in zip(S_list, D_list):
+        nx = Si.A.shape[0]
+        Ag = np.vstack((np.hstack((Di.A, np.zeros((Di.A.shape[0], nx)))), np.hstack((Si.A, Si.B, -np.eye(nx))),
+                        np.hstack((-Si.A, -Si.B, np.eye(nx)))))
+        graphs.append((Ag, np.concatenate((Di.b, -Si.c, Si.c))))
+    import pympc.optimization.programs as ref_programs
+    worst = 0.0
+    for i, (Ai, bi) in enumerate(graphs):
+        for j, (Aj, bj) in enumerate(graphs):
+            mij = []
+            for k in range(Ai.shape[0]):
+                sol, ok = certified_call(ref_programs.linear_program, -Ai[k], Aj, bj)
+                v = -sol['min'] - bi[k]
+                r = scipy.optimize.linprog(-Ai[k], A_ub=Aj, b_ub=bj, bounds=(None, None), method="highs")
+                assert r.status == 0
+                worst = max(worst, abs(v - (-r.fun - bi[k])))
+                mij.append(0. if abs(v) < 1e-6 else v)
+            out["graph_m_%d_%d" % (i, j)] = np.array(mij)
+    print("  graph big-Ms: max |reference - HiGHS| = %.2e" % worst)
+    assert worst < 1e-6
     np.savez_compressed(os.path.join(HERE, "hybrid_bigm.npz"), **out)
 
 

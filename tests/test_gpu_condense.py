@@ -199,6 +199,14 @@ def test_hybrid_bigM_vs_reference_golden():
                 assert np.allclose(got[i][j], ref, rtol=1e-7, atol=1e-7), (name, i, j)
     # the tightest choice: in its own domain a mode's constraints need no relaxation (gamma_ii <= 0)
     assert all(gamma[i][i].max() <= 1e-9 for i in range(3))
+    # big-Ms over the graphs of the dynamics (examples/pwa_from_urdf/utils.py:349-389), values from the reference's LP path
+    from pympc_amd.control.controllers import big_m, graph_representation
+    m = big_m(graph_representation(S))
+    for i in range(3):
+        for j in range(3):
+            ref = h["graph_m_%d_%d" % (i, j)]
+            assert m[i][j].shape == ref.shape and np.allclose(m[i][j], ref, rtol=1e-7, atol=1e-7), (i, j)
+            assert np.all((m[i][j] == 0.) == (ref == 0.))
     # an unbounded domain has no big-M
     bad = PieceWiseAffineSystem.__new__(PieceWiseAffineSystem)
     bad.affine_systems = systems

@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Sums rocprofv3 counter_collection CSVs per dispatch and averages over the dispatches of one kernel.
 
-    python benchmarks/pmc_summary.py <kernel substring> <dir> [<dir> ...]  -> JSON {counter: mean per launch}
+    python benchmarks/pmc_summary.py [--steps N] <kernel substring> <dir> [<dir> ...]
+      -> JSON {counter: mean per dispatch, "by_grid": {grid size: {counter: mean per dispatch}},
+               "per_step": {counter: sum over ALL matching dispatches / N}}     (per_step only with --steps)
+
+One step of the headline path may launch the same kernel twice (a small learning pass and the main pass), so the
+means are also given per grid size, and per step of the profiled program when the number of steps is named.
 """
 import csv
 import glob
@@ -11,22 +16,43 @@ import sys
 from collections import defaultdict
 
 
-def summarise(kernel, dirs):
+def summarise(kernel, dirs, steps=None):
     out = {}
+    by_grid = defaultdict(dict)
+    per_step = {}
     for d in dirs:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             per = defaultdict(lambda: defaultdict(float))
+            grid_of = {}
             with open(path) as f:
                 for row in csv.DictReader(f):
                     if kernel not in row.get("Kernel_Name", ""):
                         continue
                     per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+                    grid_of[row["Dispatch_Id"]] = row.get("Grid_Size", "?")
             for name, disp in per.items():
                 vals = list(disp.values())
                 out[name] = sum(vals) / len(vals)
                 out[name + "__launches"] = len(vals)
+                if steps:
+                    per_step[name] = sum(vals) / steps
+                groups = defaultdict(list)
+                for did, v in disp.items():
+                    groups[grid_of[did]].append(v)
+                for g, vs in groups.items():
+                    by_grid[g][name] = sum(vs) / len(vs)
+                    by_grid[g][name + "__launches"] = len(vs)
+    if len(by_grid) > 1:
+        out["by_grid"] = {g: by_grid[g] for g in sorted(by_grid)}
+    if steps:
+        out["per_step"] = per_step
     return out
 
 
 if __name__ == "__main__":
-    print(json.dumps(summarise(sys.argv[1], sys.argv[2:]), indent=1, sort_keys=True))
+    args = sys.argv[1:]
+    steps = None
+    if args and args[0] == "--steps":
+        steps = int(args[1])
+        args = args[2:]
+    print(json.dumps(summarise(args[0], args[1:], steps), indent=1, sort_keys=True))

@@ -16,10 +16,10 @@ for s in 0.3 1.0; do
 done
 run rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY -d "$OUT/pmc_sq1" -- python3 benchmarks/qp_launch.py 0.3 3
 run rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT/pmc_sq2" -- python3 benchmarks/qp_launch.py 0.3 3
-python3 benchmarks/pmc_summary.py qp_solve_kernel "$OUT/pmc_fetch_0.3" "$OUT/pmc_write_0.3" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_s03.json"
-python3 benchmarks/pmc_summary.py qp_solve_kernel "$OUT/pmc_fetch_1.0" "$OUT/pmc_write_1.0" > "$OUT/pmc_s10.json"
-python3 benchmarks/pmc_summary.py mpqp_screen_kernel "$OUT/pmc_fetch_0.3" "$OUT/pmc_write_0.3" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_screen_s03.json"
-python3 benchmarks/pmc_summary.py mpqp_screen_kernel "$OUT/pmc_fetch_1.0" "$OUT/pmc_write_1.0" > "$OUT/pmc_screen_s10.json"
+python3 benchmarks/pmc_summary.py --steps 3 qp_solve_kernel "$OUT/pmc_fetch_0.3" "$OUT/pmc_write_0.3" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_s03.json"
+python3 benchmarks/pmc_summary.py --steps 3 qp_solve_kernel "$OUT/pmc_fetch_1.0" "$OUT/pmc_write_1.0" > "$OUT/pmc_s10.json"
+python3 benchmarks/pmc_summary.py --steps 3 mpqp_screen_kernel "$OUT/pmc_fetch_0.3" "$OUT/pmc_write_0.3" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_screen_s03.json"
+python3 benchmarks/pmc_summary.py --steps 3 mpqp_screen_kernel "$OUT/pmc_fetch_1.0" "$OUT/pmc_write_1.0" > "$OUT/pmc_screen_s10.json"
 find "$OUT/trace_bench" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bench.csv" \;
 find "$OUT/trace_configs" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_configs.csv" \;
 # keep only the summaries (the raw traces are large)

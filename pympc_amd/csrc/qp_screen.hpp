@@ -240,257 +240,6 @@ __device__ __forceinline__ int screen_stage(const SolveParams &P, cdouble_ptr m0
     return kScreenPunt;
 }
 
-// ------------------------------------------------------------------------------------------------ generic stage
-// Passive sets of 3 .. kScreenKMax columns, one Lawson-Hanson step per pass: the entry's last column is the one that
-// just entered.  Coefficients y on the passive set from the Gram matrix (LDL' of G = Gr[P][P], as above).  If one of
-// them is not positive the step is Lawson-Hanson's secondary loop: interpolate from the previous coefficients (those of
-// the set without the new column, recomputed from the leading block of the same factorisation) to the first zero,
-// drop the columns that reached it, solve again on what is left (one such round per pass; a second one, a new column
-// whose own coefficient is not positive, or a small pivot send the state to the wave kernel).  Then the dual sweep:
-// optimal -> outputs; otherwise the set grows by the best column and goes back into the queue.
-constexpr int kScreenKMax = 6;
-
-template <int KM>
-struct LaneSolve {
-    double lam[KM];   // multipliers -(G^-1 m_P)
-    double tq;        // m_P'G^-1 m_P
-    bool ok;          // pivots fine
-};
-
-// LDL' solve on the first K (<= KM) entries of cols (per lane).  mP: m(x) on those columns.
-template <int KM>
-__device__ __forceinline__ LaneSolve<KM> lane_gram_solve(const SolveParams &P, const int (&cols)[KM], int K, const double (&mP)[KM],
-                                                         LaneSolve<KM> *lead /* solution on the first K - 1 columns, or null */)
-{
-    const WsLayout &L = P.L;
-    const int mp = L.mp;
-    double D[KM], Lm[KM][KM], v[KM], z[KM];
-    LaneSolve<KM> S;
-    S.ok = true;
-#pragma unroll
-    for (int a = 0; a < KM; ++a) {
-        const bool ina = a < K;
-        const int ca = ina ? cols[a] : 0;
-        const double gaa = P.ws[L.cn + ca];
-        double d = gaa;
-#pragma unroll
-        for (int b = 0; b < a; ++b) {
-            double g = P.gram[(size_t)ca * mp + ((b < K) ? cols[b] : 0)];
-#pragma unroll
-            for (int c = 0; c < b; ++c) g = fma(-Lm[a][c] * D[c], Lm[b][c], g);
-            Lm[a][b] = ina ? fast_div(g, D[b]) : 0.0;
-            d = fma(-Lm[a][b] * D[b], Lm[a][b], d);
-        }
-        S.ok = S.ok && (!ina || d > kScreenPivotMin * gaa);
-        D[a] = (ina && d > 0.0) ? d : 1.0;
-    }
-#pragma unroll
-    for (int a = 0; a < KM; ++a) {
-        double s = (a < K) ? mP[a] : 0.0;
-#pragma unroll
-        for (int b = 0; b < a; ++b) s = fma(-Lm[a][b], v[b], s);
-        v[a] = s;
-    }
-    // the same forward substitution serves the leading (K - 1) block: only the back substitution differs
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && !lead) break;
-        const int Kp = pass == 0 ? K : K - 1;
-        double tq = 0.0;
-#pragma unroll
-        for (int a = 0; a < KM; ++a) {
-            z[a] = (a < Kp) ? fast_div(v[a], D[a]) : 0.0;
-            tq = fma((a < Kp) ? v[a] : 0.0, z[a], tq);
-        }
-#pragma unroll
-        for (int a = KM - 1; a >= 0; --a) {
-            double s = z[a];
-#pragma unroll
-            for (int b = a + 1; b < KM; ++b) s = fma(-Lm[b][a], (b < Kp) ? z[b] : 0.0, s);
-            z[a] = (a < Kp) ? s : 0.0;
-        }
-        LaneSolve<KM> &T = pass == 0 ? S : *lead;
-        T.tq = tq;
-#pragma unroll
-        for (int a = 0; a < KM; ++a) T.lam[a] = -z[a];
-    }
-    return S;
-}
-
-template <int PD, int KM>
-__device__ __forceinline__ void screen_write_k(const SolveParams &P, cdouble_ptr tab, long long prob, const double (&x)[PD],
-                                               int K, const int (&cols)[KM], const double (&lam)[KM], double tq, int outer, int inner)
-{
-    const WsLayout &L = P.L;
-    const int n = P.n, m = P.m, nw = (m + 31) / 32;
-    P.status[prob] = kStatusOptimal;
-    if (P.iters) { P.iters[2 * prob] = outer; P.iters[2 * prob + 1] = inner; }
-    if (P.argmin)
-        for (int i = 0; i < P.n_out; ++i) {
-            double ui = tab[L.u0 + i];
-#pragma unroll
-            for (int q = 0; q < PD; ++q) ui = fma(tab[L.Ku + (size_t)i * PD + q], x[q], ui);
-#pragma unroll
-            for (int l = 0; l < KM; ++l)
-                if (l < K) ui = fma(-lam[l], P.ws[L.T + (size_t)cols[l] * n + i], ui);
-            P.argmin[prob * P.n_out + i] = ui;
-        }
-    if (P.vmin) P.vmin[prob] = (tab[L.s0] + vunc_terms<PD>(tab, L, x)) + 0.5 * tq;
-    if (P.active)
-        for (int e = 0; e < nw; ++e) {
-            uint32_t word = 0u;
-#pragma unroll
-            for (int l = 0; l < KM; ++l)
-                if (l < K && e == (cols[l] >> 5) && lam[l] > P.tol) word |= 1u << (cols[l] & 31);
-            P.active[prob * nw + e] = word;
-        }
-    if (P.mult)
-        for (int j = 0; j < m; ++j) {
-            double v = 0.0;
-#pragma unroll
-            for (int l = 0; l < KM; ++l)
-                if (l < K && j == cols[l]) v = lam[l];
-            P.mult[prob * m + j] = v;
-        }
-}
-
-// One generic pass for the state of this lane.  In: K columns (the last one new), outer / inner iteration counters so
-// far.  Returns kScreenDone / kScreenNext (cols, K updated with the next column appended) / kScreenPunt.
-template <int PD, int KM>
-__device__ __forceinline__ int screen_stage_k(const SolveParams &P, cdouble_ptr m0, cdouble_ptr Gm, cdouble_ptr cn, cdouble_ptr tab,
-                                              bool act, long long prob, int (&cols)[KM], int &K, int &outer, int &inner)
-{
-    const WsLayout &L = P.L;
-    const int m = P.m, mp = L.mp;
-    double x[PD];
-#pragma unroll
-    for (int q = 0; q < PD; ++q) x[q] = act ? P.X[prob * P.x_stride + q] : 0.0;
-    if (!act) K = 0;
-    double mP[KM];
-#pragma unroll
-    for (int l = 0; l < KM; ++l) {
-        if (l >= K) cols[l] = 0;
-        double s = P.ws[L.m0 + cols[l]];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) s = fma(P.ws[L.Gm + (size_t)q * mp + cols[l]], x[q], s);
-        mP[l] = s;
-    }
-    bool ok = act;
-    LaneSolve<KM> lead;
-    LaneSolve<KM> S = lane_gram_solve<KM>(P, cols, K, mP, &lead);
-    ok = ok && S.ok;
-    ++inner;
-    bool drop = false;
-#pragma unroll
-    for (int l = 0; l < KM; ++l) drop = drop || (l < K && !(S.lam[l] > 0.0));
-    if (ok && drop) {
-        // Lawson-Hanson secondary loop, one round: y_old on the set without the new column (0 for the new one),
-        // alpha = min over the non-positive coefficients of y_old / (y_old - y)
-        const double g_new = fast_div(1.0, 1.0 + S.tq), g_old = fast_div(1.0, 1.0 + lead.tq);
-        double yo[KM], yn[KM];
-        double alpha = 2.0;
-        bool lead_ok = true;
-#pragma unroll
-        for (int l = 0; l < KM; ++l) {
-            yo[l] = (l < K - 1) ? lead.lam[l] * g_old : 0.0;
-            yn[l] = (l < K) ? S.lam[l] * g_new : 0.0;
-            lead_ok = lead_ok && !(l < K - 1 && !(yo[l] > 0.0));
-            if (l < K && !(yn[l] > 0.0)) alpha = fmin(alpha, fast_div(yo[l], yo[l] - yn[l]));
-        }
-        // the new column's own coefficient is not positive (alpha = 0), or the previous set was not a solution: not ours
-        ok = ok && lead_ok && (alpha > 0.0) && (alpha <= 1.0);
-        int Kn = 0;
-        int cn2[KM];
-        double mn2[KM];
-#pragma unroll
-        for (int l = 0; l < KM; ++l) { cn2[l] = 0; mn2[l] = 0.0; }
-#pragma unroll
-        for (int l = 0; l < KM; ++l) {
-            const double yi = fma(alpha, yn[l] - yo[l], yo[l]);
-            const bool keep = l < K && yi > 0.0 && (yn[l] > 0.0 || fast_div(yo[l], yo[l] - yn[l]) > alpha);
-            if (keep) {
-#pragma unroll
-                for (int t = 0; t < KM; ++t)
-                    if (t == Kn) { cn2[t] = cols[l]; mn2[t] = mP[l]; }
-                ++Kn;
-            }
-        }
-        ok = ok && Kn >= 1 && Kn < K;
-#pragma unroll
-        for (int l = 0; l < KM; ++l) { cols[l] = cn2[l]; mP[l] = mn2[l]; }
-        K = ok ? Kn : 0;
-        S = lane_gram_solve<KM>(P, cols, K, mP, nullptr);
-        ++inner;
-        ok = ok && S.ok;
-#pragma unroll
-        for (int l = 0; l < KM; ++l) ok = ok && !(l < K && !(S.lam[l] > 0.0));   // a second round: the wave kernel's
-    }
-    const double gamma = fast_div(1.0, 1.0 + S.tq);
-    ok = ok && (gamma > kScreenGammaMin);
-    double y[KM];
-#pragma unroll
-    for (int l = 0; l < KM; ++l) {
-        y[l] = (l < K) ? S.lam[l] * gamma : 0.0;
-        ok = ok && (y[l] < kGramMaxCoeff);
-    }
-    // ---- dual sweep
-    bool more = false;
-    double best = -1.0;
-    int jb = 0;
-    const double ng = -gamma;
-    for (int j = 0; j < mp && __ballot(ok) != 0ull; j += 4) {
-        double mv[4], g[KM][4];
-#pragma unroll
-        for (int l = 0; l < KM; ++l)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) g[l][u] = P.gram[(size_t)(j + u) * mp + cols[l]];   // Gr symmetric: column c_l of row j
-#pragma unroll
-        for (int u = 0; u < 4; ++u) mv[u] = m0[j + u];
-#pragma unroll
-        for (int q = 0; q < PD; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
-        unsigned self = 0u;
-#pragma unroll
-        for (int l = 0; l < KM; ++l)
-            if (l < K && (cols[l] >> 2) == (j >> 2)) self |= 1u << (cols[l] & 3);
-        double wv[4];
-        bool pos4 = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            double w = ng * mv[u];
-#pragma unroll
-            for (int l = 0; l < KM; ++l) w = fma(-y[l], g[l][u], w);
-            wv[u] = (((self >> u) & 1u) || j + u >= m) ? -1.0 : w;
-            pos4 = pos4 || (wv[u] > 0.0);
-        }
-        more = more || pos4;
-        if (__ballot(ok && pos4) != 0ull) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double d = fma(mv[u], mv[u], cn[j + u]);
-                const double sc = (wv[u] > 0.0) ? wv[u] * wv[u] * __builtin_amdgcn_rcp(d) : -1.0;
-                if (sc > best) { best = sc; jb = j + u; }
-            }
-        }
-    }
-    if (!act) return kScreenDone;
-    if (ok && !more) {
-        screen_write_k<PD, KM>(P, tab, prob, x, K, cols, S.lam, S.tq, outer, inner);
-        return kScreenDone;
-    }
-    if (ok && K < KM && best > 0.0) {
-#pragma unroll
-        for (int t = 0; t < KM; ++t)
-            if (t == K) cols[t] = jb;
-        ++K;
-        ++outer;
-        return kScreenNext;
-    }
-    P.status[prob] = kStatusPending;
-    return kScreenPunt;
-}
-
 // append (id, cols[0..K]) of the lanes with `push` to a queue in LDS (whole workgroup; no barrier inside)
 template <int KC>
 __device__ __forceinline__ void screen_push(bool push, int *cnt, int *qid, int (*qcol)[KC], int cap_unused, int id,

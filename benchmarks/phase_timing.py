@@ -30,6 +30,12 @@ nit = it[w, 0].sum()
 for i, nme in enumerate(names):
     print("%-12s %8.0f cycles/QP  %5.1f %%   per outer iteration: %7.0f" % (nme, ph[w, i].mean(), 100 * ph[w, i].sum() / tot, ph[w, i].sum() / nit))
 print("total per outer iteration: %.0f cycles" % (tot / nit))
+g = w & (it[:, 0] <= 8)   # (debug builds with the Gram kernel: its phases are setup, pick, trial, border+solve, secondary, sweep, exit, outputs)
+gn = ["setup m(x)", "pick", "trial", "border+solve", "secondary", "sweep", "(exit)", "outputs"]
+if g.sum():
+    print("Gram kernel states: %d, mean outer %.2f" % (g.sum(), it[g, 0].mean()))
+    for i, nme in enumerate(gn):
+        print("  %-12s %8.0f cycles/QP   per outer iteration: %7.0f" % (nme, ph[g, i].mean(), ph[g, i].sum() / it[g, 0].sum()))
 for k in (3, 4, 6, 8, 12, 16):
     sel = w & (it[:, 0] == k)
     if sel.sum():

@@ -19,6 +19,8 @@ run rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ
 python3 benchmarks/pmc_summary.py --steps 3 qp_solve_kernel "$OUT/pmc_fetch_0.3" "$OUT/pmc_write_0.3" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_s03.json"
 python3 benchmarks/pmc_summary.py --steps 3 qp_solve_kernel "$OUT/pmc_fetch_1.0" "$OUT/pmc_write_1.0" > "$OUT/pmc_s10.json"
 python3 benchmarks/pmc_summary.py --steps 3 mpqp_screen_kernel "$OUT/pmc_fetch_0.3" "$OUT/pmc_write_0.3" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_screen_s03.json"
+python3 benchmarks/pmc_summary.py --steps 3 mpqp_gram_kernel "$OUT/pmc_fetch_0.3" "$OUT/pmc_write_0.3" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_gram_s03.json"
+python3 benchmarks/pmc_summary.py --steps 3 mpqp_gram_kernel "$OUT/pmc_fetch_1.0" "$OUT/pmc_write_1.0" > "$OUT/pmc_gram_s10.json"
 python3 benchmarks/pmc_summary.py --steps 3 mpqp_screen_kernel "$OUT/pmc_fetch_1.0" "$OUT/pmc_write_1.0" > "$OUT/pmc_screen_s10.json"
 find "$OUT/trace_bench" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bench.csv" \;
 find "$OUT/trace_configs" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_configs.csv" \;

@@ -96,6 +96,15 @@ __device__ __forceinline__ double wsum(double v)
     v += dpp_f64<kDppMirror>(v);
     return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
 }
+// sum of lanes 0 .. 7 (the other lanes of the first row of 16 may hold anything; lanes >= 8 of the addend must be 0 only
+// if they fall into lanes 0 .. 7's butterfly: they do not)
+__device__ __forceinline__ double wsum8(double v)
+{
+    v += dpp_f64<kDppXor1>(v);
+    v += dpp_f64<kDppXor2>(v);
+    v += dpp_f64<kDppHalfMirror>(v);
+    return lane_f64(v, 0);
+}
 // three sums at once: the three butterflies are independent, written in lockstep so that they overlap in the pipeline
 __device__ __forceinline__ void wsum3(double &a, double &b, double &c)
 {

@@ -16,6 +16,7 @@
 #include "qp_prepare.hpp"
 #include "qp_wave.hpp"
 #include "qp_screen.hpp"
+#include "qp_gram.hpp"
 #include "ws_layout.hpp"
 
 using namespace pympc;
@@ -61,9 +62,9 @@ int check_launch(const char *what)
 constexpr int kMaxDevices = 64;
 struct LdsGrant { const void *fn; int dev; size_t bytes; };
 template <typename K>
-int allow_lds(K kernel, size_t bytes)
+int allow_lds(K kernel, size_t bytes, size_t static_bytes = 0)
 {
-    if (bytes <= 64 * 1024) return 0;
+    if (bytes + static_bytes <= 64 * 1024) return 0;   // (bytes: dynamic LDS; static_bytes: what the kernel declares itself)
     static std::mutex mu;
     static LdsGrant grants[128];
     static int ngrants = 0;
@@ -157,7 +158,10 @@ int check_prep(const PrepGeom &G, int n, int m, int p)
 // status array, which the main launch overwrites.  With a table that is already warm its infeasible states are
 // rejected at once and it costs one short launch.
 constexpr long long kLearnMinBatch = 131072;
-constexpr long long kLearnStates = 8192;
+#ifndef PYMPC_LEARN_STATES
+#define PYMPC_LEARN_STATES 8192
+#endif
+constexpr long long kLearnStates = PYMPC_LEARN_STATES;
 
 // Common launch geometry of the solve kernel.
 int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t st, bool learn_pass = false)
@@ -227,6 +231,23 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
             }
 #undef PYMPC_SCREEN_CASE
             if (int rc = check_launch("mpqp_screen_kernel")) return rc;
+            // Gram-form pass (qp_gram.hpp): what the lane path left pending and ends with up to kGramK active constraints
+            // is finished here, without the matrix in LDS; the rest stays pending for the solve kernel below
+            if (P.gram && !P.rhs && !P.raw && mt <= 8) {
+                SolveParams G = P;
+                G.chunk = kGramSlice;
+                const size_t gbytes = gram_lds_doubles(p, P.L) * sizeof(double);   // <= 10 * 512 * 8 + tables: below 64 KiB
+                const long long gslices = (P.B + kGramSlice - 1) / kGramSlice;
+                const long long gwant = (gslices + kGramThreads / 64 - 1) / (kGramThreads / 64);
+                const long long gg = gwant < ncu ? gwant : ncu;
+                switch (mt) {
+                case 2: hipLaunchKernelGGL(mpqp_gram_kernel<2>, dim3((unsigned)gg), dim3(kGramThreads), gbytes, st, G); break;
+                case 4: hipLaunchKernelGGL(mpqp_gram_kernel<4>, dim3((unsigned)gg), dim3(kGramThreads), gbytes, st, G); break;
+                case 6: hipLaunchKernelGGL(mpqp_gram_kernel<6>, dim3((unsigned)gg), dim3(kGramThreads), gbytes, st, G); break;
+                case 8: hipLaunchKernelGGL(mpqp_gram_kernel<8>, dim3((unsigned)gg), dim3(kGramThreads), gbytes, st, G); break;
+                }
+                if (int rc = check_launch("mpqp_gram_kernel")) return rc;
+            }
         }
     } else {
         P.chunk = (int)chunk;

@@ -220,7 +220,13 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
             P.screened = 1;
             // persistent workgroups, two per CU, each walking over whole tiles of states (qp_screen.hpp); the grid is
             // evened out so that every workgroup gets the same number of tiles (+- 1)
-            const long long tile = (long long)kScreenThreads * (p <= 4 ? 2 : 1);   // = kScreenThreads * screen_states_per_lane<p>()
+            long long tile = (long long)kScreenThreads * (p <= 4 ? 2 : 1);   // = kScreenThreads * screen_states_per_lane<p>()
+            if (P.B < 2LL * ncu * tile) {   // a small batch: smaller tiles (whole wavefronts), so that it still spreads over the chip
+                const long long per = (P.B + 2LL * ncu - 1) / (2LL * ncu);
+                const long long t64 = (per + 63) / 64 * 64;
+                if (t64 < tile) tile = t64 < 64 ? 64 : t64;
+            }
+            P.screen_tile = (int)tile;
             const long long ntile = (P.B + tile - 1) / tile;
             const long long rounds = (ntile + 2LL * ncu - 1) / (2LL * ncu);
             const long long sg = (ntile + rounds - 1) / rounds;
@@ -233,11 +239,15 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
             if (int rc = check_launch("mpqp_screen_kernel")) return rc;
             // Gram-form pass (qp_gram.hpp): what the lane path left pending and ends with up to kGramK active constraints
             // is finished here, without the matrix in LDS; the rest stays pending for the solve kernel below
-            if (P.gram && !P.rhs && !P.raw && mt <= 8) {
+            // (batches too small to keep the chip busy pay for its launch and staging more than it saves the solve kernel)
+            constexpr long long kGramMinBatch = 8192;
+            if (P.gram && !P.rhs && !P.raw && mt <= 8 && P.B >= kGramMinBatch) {
                 SolveParams G = P;
-                G.chunk = kGramSlice;
+                int gslice = kGramSlice;   // states per ticket; smaller while the batch does not give every wave a slice
+                while (gslice > 1 && P.B < (long long)gslice * (kGramThreads / 64) * ncu) gslice >>= 1;
+                G.chunk = gslice;
                 const size_t gbytes = gram_lds_doubles(p, P.L) * sizeof(double);   // <= 10 * 512 * 8 + tables: below 64 KiB
-                const long long gslices = (P.B + kGramSlice - 1) / kGramSlice;
+                const long long gslices = (P.B + gslice - 1) / gslice;
                 const long long gwant = (gslices + kGramThreads / 64 - 1) / (kGramThreads / 64);
                 const long long gg = gwant < ncu ? gwant : ncu;
                 switch (mt) {

@@ -313,9 +313,10 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
         __syncthreads();
     };
 
-    const long long ntile = (P.B + TILE - 1) / TILE;
+    const int TS = P.screen_tile;   // states per tile: TILE, or less (a multiple of 64) so that a small batch still spreads over the chip
+    const long long ntile = (P.B + TS - 1) / TS;
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const long long base = tile * TILE;
+        const long long base = tile * TS;
         double x[S][PD];
         bool valid[S], hit[S], neg[S];
         double best[S];
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const long long prob = base + (long long)s * NT + tid;
-            valid[s] = prob < P.B;
+            valid[s] = s * NT + tid < TS && prob < P.B;
 #pragma unroll
             for (int q = 0; q < PD; ++q) x[s][q] = valid[s] ? P.X[prob * P.x_stride + q] : 0.0;
             hit[s] = false;

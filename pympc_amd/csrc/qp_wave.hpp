@@ -53,6 +53,7 @@ struct SolveParams {
     int32_t *iters;             // [B x 2] or null
     int chunk;                  // problems per workgroup; SHARED with persist: problems per interleaved slice
     int screened;               // SHARED: status[] was initialised by mpqp_screen_kernel (kStatusPending = still to solve)
+    int screen_tile;            // states per tile of mpqp_screen_kernel (<= its compile-time tile; smaller for small batches)
     int persist;                // SHARED: the grid is one workgroup per CU, workgroup g owns slices g, g + G, g + 2 G, ...
     int wave_doubles;           // per-wave LDS doubles
     // raw NNLS (pympc_nnls_batch: scipy.optimize.nnls on a general matrix and right-hand side): rhs [B x (n + 1)] replaces

@@ -77,16 +77,41 @@ __global__ void point_location_kernel(PlParams P)
     const long long stride = (long long)gridDim.x * blockDim.x;
     // every lane of a wave runs the same number of grid-stride rounds (wave-uniform loop bound)
     const long long base0 = (long long)blockIdx.x * blockDim.x + (tid & ~63);
+    // The kernel is bound by the chain of dependent memory round trips per batch of 64 points (points -> cells -> rows
+    // -> law), so everything that does not depend on the points is fetched ahead: the next batch's points, and (lane
+    // <-> region) the boxes and row ranges of the first 64 regions.
+    const int lane = tid & 63;
+    double pbox_lo[PD], pbox_hi[PD];
+    int prp0 = 0, prp1 = 0;
+    {
+        const int rl = min(lane, P.nreg - 1);
+        prp0 = P.row_ptr[rl];
+        prp1 = P.row_ptr[rl + 1];
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            pbox_lo[q] = P.box ? P.box[(size_t)rl * 2 * PD + q] : 0.0;
+            pbox_hi[q] = P.box ? P.box[(size_t)rl * 2 * PD + PD + q] : 0.0;
+        }
+    }
+    double xn[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) xn[q] = (base0 + lane < P.B) ? P.X[(base0 + lane) * PD + q] : 0.0;
     for (long long base = base0; base < P.B; base += stride) {
-        const long long pt = base + (tid & 63);
+        const long long pt = base + lane;
         const bool valid = pt < P.B;
         double x[PD];
 #pragma unroll
-        for (int q = 0; q < PD; ++q) x[q] = valid ? P.X[pt * PD + q] : 0.0;
+        for (int q = 0; q < PD; ++q) x[q] = xn[q];
+        {
+            const long long nx = pt + stride;
+#pragma unroll
+            for (int q = 0; q < PD; ++q) xn[q] = (nx < P.B) ? P.X[nx * PD + q] : 0.0;
+        }
         int found = -1;
         // axis-aligned hull of the wave's points: a region whose box misses it holds none of them
         double wlo[PD], whi[PD];
-        if (box || P.grid_masks) {
+        constexpr bool kCorners = PD <= 3;   // hull-corner tests below: 2^p corners per row
+        if (box || P.grid_masks || kCorners) {
 #pragma unroll
             for (int q = 0; q < PD; ++q) {
                 wlo[q] = wmin(valid ? x[q] : 1.0e300);
@@ -129,12 +154,27 @@ __global__ void point_location_kernel(PlParams P)
                 cand = wor64(mk);
                 if (cand == 0ull) continue;
             }
-            if (box) {
-                const int rl = r0 + (tid & 63);
-                bool hit = rl < P.nreg;
-                const double *lo = P.box + (size_t)(hit ? rl : 0) * 2 * PD, *hi = lo + PD;   // lane <-> region: vector loads
+            // lane <-> region: box and row range of region r0 + lane (the first block's were fetched ahead)
+            int rp0 = prp0, rp1 = prp1;
+            double blo[PD], bhi[PD];
 #pragma unroll
-                for (int q = 0; q < PD; ++q) hit = hit && (lo[q] <= whi[q]) && (hi[q] >= wlo[q]);
+            for (int q = 0; q < PD; ++q) { blo[q] = pbox_lo[q]; bhi[q] = pbox_hi[q]; }
+            if (r0 > 0) {
+                const int rl = min(r0 + lane, P.nreg - 1);
+                rp0 = P.row_ptr[rl];
+                rp1 = P.row_ptr[rl + 1];
+                if (box) {
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) {
+                        blo[q] = P.box[(size_t)rl * 2 * PD + q];
+                        bhi[q] = P.box[(size_t)rl * 2 * PD + PD + q];
+                    }
+                }
+            }
+            if (box) {
+                bool hit = r0 + lane < P.nreg;
+#pragma unroll
+                for (int q = 0; q < PD; ++q) hit = hit && (blo[q] <= whi[q]) && (bhi[q] >= wlo[q]);
                 cand &= __ballot(hit);
             } else if (P.nreg - r0 < 64) {
                 cand &= (1ull << (P.nreg - r0)) - 1ull;
@@ -144,6 +184,44 @@ __global__ void point_location_kernel(PlParams P)
                 cand &= cand - 1ull;
                 bool inside = valid && found < 0;
                 if (__ballot(inside) == 0ull) break;
+                if (kCorners) {
+                    // The wave's points are neighbours of a grid and a region is convex: it holds ALL of them iff it holds
+                    // the corners of their hull, and NONE of them if one row is violated at every corner.  Both tests run
+                    // lane <-> row (64 rows at a time, 2^p corners each) instead of every lane walking all rows, and only
+                    // decide with a margin far above the rounding of the row expression (1e-12 relative to its terms);
+                    // whatever they leave open takes the per-point scan below, so the first-hit result is unchanged.
+                    const int i0 = lane_i32(rp0, r - r0), i1 = lane_i32(rp1, r - r0);
+                    bool all_in = true, any_out = false;
+                    for (int c0 = i0; c0 < i1; c0 += 64) {
+                        const int i = c0 + lane;
+                        const bool on = i < i1;
+                        const double *ar = P.A + (size_t)(on ? i : i0) * PD;
+                        const double bb = P.b[on ? i : i0];
+                        double a[PD], mag = fabs(bb);
+#pragma unroll
+                        for (int q = 0; q < PD; ++q) {
+                            a[q] = ar[q];
+                            mag = fma(fabs(a[q]), fmax(fabs(wlo[q]), fabs(whi[q])), mag);
+                        }
+                        const double marg = 1e-12 * mag;
+                        bool in_all = true, out_all = true;
+#pragma unroll
+                        for (int c = 0; c < (1 << PD); ++c) {
+                            double sc = -bb;
+#pragma unroll
+                            for (int q = 0; q < PD; ++q) sc = fma(a[q], ((c >> q) & 1) ? whi[q] : wlo[q], sc);
+                            in_all = in_all && (sc <= P.tol - marg);
+                            out_all = out_all && (sc >= P.tol + marg);
+                        }
+                        all_in = all_in && (__ballot(on && !in_all) == 0ull);
+                        any_out = any_out || (__ballot(on && out_all) != 0ull);
+                    }
+                    if (any_out) continue;
+                    if (all_in) {
+                        if (inside) found = r;
+                        continue;
+                    }
+                }
                 if (box) {
                     const cdouble_ptr lo = box + (size_t)r * 2 * PD, hi = lo + PD;
 #pragma unroll
@@ -152,8 +230,8 @@ __global__ void point_location_kernel(PlParams P)
                 }
                 // rows in batches of kPlRows: all loads of a batch are issued before the first FMA (a row-at-a-time loop
                 // pays one memory round trip per row); the clamped repeats of the last row test the same condition again
-                const int i1 = __builtin_amdgcn_readfirstlane(row_ptr[r + 1]);
-                for (int i = __builtin_amdgcn_readfirstlane(row_ptr[r]); i < i1; i += kPlRows) {
+                const int i1 = lane_i32(rp1, r - r0);
+                for (int i = lane_i32(rp0, r - r0); i < i1; i += kPlRows) {
                     double a[kPlRows][PD], bb[kPlRows];
 #pragma unroll
                     for (int u = 0; u < kPlRows; ++u) {
@@ -174,7 +252,31 @@ __global__ void point_location_kernel(PlParams P)
                 if (inside) found = r;
             }
         }
-        if (valid) {
+        // every point of the wave in ONE region (the common case on a grid): the region's law comes through scalar loads
+        const int f0 = __builtin_amdgcn_readfirstlane(found);
+        if (f0 >= 0 && __ballot(valid && found != f0) == 0ull) {
+            if (valid) {
+                const cdouble_ptr Vxx = as_const(P.Vxx) + (size_t)f0 * PD * PD, Vx = as_const(P.Vx) + (size_t)f0 * PD;
+                double qd = 0.0, lin = 0.0;
+#pragma unroll
+                for (int i = 0; i < PD; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) s = fma(x[q], Vxx[q * PD + i], s);
+                    qd = fma(s, x[i], qd);
+                    lin = fma(Vx[i], x[i], lin);
+                }
+                P.idx[pt] = f0;
+                P.V[pt] = .5 * qd + lin + as_const(P.V0)[f0];
+                const cdouble_ptr u0 = as_const(P.u0) + (size_t)f0 * P.nu, ux = as_const(P.ux) + (size_t)f0 * P.nu * PD;
+                for (int i = 0; i < P.nu; ++i) {
+                    double s = u0[i];
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) s = fma(ux[i * PD + q], x[q], s);
+                    P.u[pt * P.nu + i] = s;
+                }
+            }
+        } else if (valid) {
             P.idx[pt] = found;
             double V = nanv;
             if (found >= 0) {

@@ -124,9 +124,10 @@ class MpqpBatch(object):
         nx = self.tables.nx
         return S[:, :nx].copy(), S[:, nx:-1].copy(), S[:, -1].copy()
 
-    def solve(self, x, tol=TOL, want_mult=True, want_active=True, want_iters=False):
+    def solve(self, x, tol=TOL, want_mult=True, want_active=True, want_iters=False, want_argmin=True):
         """get_mpqp(ms).solve(x) for every sequence: x [p] (shared) or [B x p].  Returns a BatchResult over the
-        padded rows (pad rows never carry a multiplier)."""
+        padded rows (pad rows never carry a multiplier).  want_argmin=False (costs only, e.g. the arg-min over mode
+        sequences): the per-sequence factorisation then skips the 40 % of its workspace that only the minimiser needs."""
         lib = _hip.load_library()
         self.check()
         dev = self.modes.device
@@ -147,7 +148,8 @@ class MpqpBatch(object):
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         B, n, m = self.B, self.n, self.m
-        out = dict(status=torch.empty(B, **i32), argmin=torch.empty((B, n), **f64), min=torch.empty(B, **f64))
+        out = dict(status=torch.empty(B, **i32), argmin=torch.empty((B, n), **f64) if want_argmin else None,
+                   min=torch.empty(B, **f64))
         out['multiplier_inequality'] = torch.empty((B, m), **f64) if want_mult else None
         out['active_bits'] = torch.empty((B, (m + 31) // 32), **i32) if want_active else None
         out['iters'] = torch.empty((B, 2), **i32) if want_iters else None

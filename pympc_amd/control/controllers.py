@@ -219,7 +219,7 @@ class HybridModelPredictiveController(object):
         relaxations for t < N, the full problem (terminal cost P, terminal set X_N) for t = N."""
         t = seqs.shape[1]
         batch = condense_batch(self.tables() if t == self.N else self._prefix_tables(), seqs)
-        res = batch.solve(x, want_mult=False, want_active=False)
+        res = batch.solve(x, want_mult=False, want_active=False, want_argmin=(t == self.N))   # (prefixes: costs only)
         V = torch.where(res.t['status'] == 0, res.t['min'], torch.full_like(res.t['min'], float('inf')))
         return V.cpu().numpy(), res
 

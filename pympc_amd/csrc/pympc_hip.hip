@@ -563,6 +563,7 @@ int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, co
     Q.Ax = Ax; Q.ax_stride = (long long)m * p;
     Q.b = b; Q.b_stride = m;
     Q.ws = ws; Q.ws_stride = (long long)L.total; Q.ws_status = ws_status;
+    Q.skip_T = argmin == nullptr;   // (the workspaces of this call are only read by the solve launch below)
     const PrepGeom G = prep_geom(n, m, Q.p, B);
     if (int rc = check_prep(G, n, m, Q.p)) return rc;
     Q.tile_rows = G.tile_rows;

@@ -30,6 +30,7 @@ struct PrepParams {
     double *ws;        long long ws_stride;
     int32_t *ws_status;
     int tile_rows;     // constraint rows staged in LDS at a time (= threads that work on rows)
+    int skip_T;        // the caller never recovers the minimiser (no argmin output): T = A H^-1 is not written (40 % of the workspace)
 };
 
 // LDS doubles of the prepare kernel: three n x (n+1) matrices (L, L^-1, H^-1), fu and Hux, and two row tiles
@@ -148,7 +149,8 @@ __global__ void qp_prepare_kernel(PrepParams P)
             }
         }
         __syncthreads();
-        for (int e = tid; e < rows * n; e += nt) ws[L.T + (size_t)row0 * n + e] = Ts[(e / n) * np + (e % n)];
+        if (!P.skip_T)
+            for (int e = tid; e < rows * n; e += nt) ws[L.T + (size_t)row0 * n + e] = Ts[(e / n) * np + (e % n)];
     }
     __syncthreads();
     // unconstrained minimiser u_unc(x) = u0 + Ku x

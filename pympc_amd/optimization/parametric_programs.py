@@ -276,6 +276,19 @@ class ExplicitSolution(object):
         nu = nu_all if nu is None else nu
         if self._table is not None and self._table['nu'] == nu:
             return self._table
+        if self._table is not None:
+            # another number of inputs (feedback vs feedforward): the regions, their boxes and the cell grid do not
+            # depend on it -- only the laws' arrays are rebuilt
+            t = dict(self._table)
+            t['nu'] = nu
+            p, n_cr = t['p'], len(crs)
+            t['ux'] = np.array([cr._u['x'][:nu] for cr in crs]).reshape(n_cr, nu, p)
+            t['u0'] = np.array([cr._u['0'][:nu] for cr in crs]).reshape(n_cr, nu)
+            t['dev'] = dict(self._table['dev'])
+            t['dev']['ux'] = _hip.to_device(t['ux'])
+            t['dev']['u0'] = _hip.to_device(t['u0'])
+            self._table = t
+            return t
         p = crs[0].polyhedron.A.shape[1]
         for cr in crs:
             if cr.polyhedron.C.shape[0] != 0:
@@ -325,10 +338,17 @@ class ExplicitSolution(object):
             A[r, :rows[r]] = t['A'][rp[r]:rp[r + 1]]
             b[r, :rows[r]] = t['b'][rp[r]:rp[r + 1]] + tol + 1.e-9
         f = np.vstack((np.eye(p), -np.eye(p)))                             # min x_i, then min -x_i
-        res = hip_lp.linear_program_batch(np.tile(f, (nreg, 1)), np.repeat(A, 2 * p, axis=0), np.repeat(b, 2 * p, axis=0),
-                                          want_argmin=False, want_mult=False, want_active=False)
-        st = res.numpy('status').reshape(nreg, 2 * p)
-        v = res.numpy('min').reshape(nreg, 2 * p)
+        # (one launch takes at most 65535 distinct matrices: larger tables go in chunks of whole regions)
+        per = max(1, 65535 // (2 * p))
+        st = np.empty((nreg, 2 * p), np.int32)
+        v = np.empty((nreg, 2 * p))
+        for r0 in range(0, nreg, per):
+            r1 = min(nreg, r0 + per)
+            res = hip_lp.linear_program_batch(np.tile(f, (r1 - r0, 1)), np.repeat(A[r0:r1], 2 * p, axis=0),
+                                              np.repeat(b[r0:r1], 2 * p, axis=0), want_argmin=False, want_mult=False,
+                                              want_active=False)
+            st[r0:r1] = res.numpy('status').reshape(r1 - r0, 2 * p)
+            v[r0:r1] = res.numpy('min').reshape(r1 - r0, 2 * p)
         lo = np.where(st[:, :p] == 0, v[:, :p], -np.inf)
         hi = np.where(st[:, p:] == 0, -v[:, p:], np.inf)
         pad = 1.e-9

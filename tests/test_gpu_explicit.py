@@ -211,3 +211,37 @@ def test_full_size_grid_properties(nb):
     assert (feas == c).mean() > .999 and agree.sum() > 5000
     assert np.allclose(Vs[agree], res.numpy('min')[agree], rtol=1e-6, atol=1e-6)
     assert np.allclose(us[agree], res.numpy('argmin')[agree][:, :1], rtol=1e-6, atol=1e-6)
+
+
+def test_table_is_reused_across_input_counts_and_boxes_come_in_chunks(nb, monkeypatch):
+    """The look-up table's regions, boxes and cell grid do not depend on how many inputs are evaluated: asking for
+    another nu rebuilds the laws only.  Bounding boxes of a table with more regions than one LP launch takes distinct
+    matrices (65535 / 2p) are computed in chunks of whole regions: same boxes as in one launch."""
+    from pympc_amd.optimization import parametric_programs as pp
+    es = nb.explicit_solution
+    es._table = None
+    t1 = es.table(nu=1)
+    calls = []
+    orig = pp.ExplicitSolution._bounding_boxes
+    monkeypatch.setattr(pp.ExplicitSolution, "_bounding_boxes", staticmethod(lambda t, tol: calls.append(1) or orig(t, tol)))
+    t_all = es.table()                                   # all inputs of the horizon
+    assert not calls and t_all['nu'] > 1 and t_all['box'] is t1['box'] and t_all['dev']['box'] is t1['dev']['box']
+    X = np.random.RandomState(3).uniform(-.4, .4, (5000, 2))
+    i_all, u_all, V_all = es.locate(X)
+    es._table = None
+    i_one, u_one, V_one = es.locate(X, nu=1)
+    assert np.array_equal(i_all.cpu().numpy(), i_one.cpu().numpy())
+    ok = i_one.cpu().numpy() >= 0
+    assert np.array_equal(u_all.cpu().numpy()[ok][:, :1], u_one.cpu().numpy()[ok])
+    # chunking
+    monkeypatch.undo()
+    ref_box = orig(es.table(), 1e-7)
+    t = es.table()
+    # (a region's box only depends on its own rows: the table split by hand into chunks of 10 regions gives the same boxes)
+    parts = []
+    for r0 in range(0, t['nreg'], 10):
+        r1 = min(t['nreg'], r0 + 10)
+        rp = t['row_ptr'][r0:r1 + 1] - t['row_ptr'][r0]
+        sub = dict(nreg=r1 - r0, p=t['p'], row_ptr=rp, A=t['A'][t['row_ptr'][r0]:t['row_ptr'][r1]], b=t['b'][t['row_ptr'][r0]:t['row_ptr'][r1]])
+        parts.append(orig(sub, 1e-7))
+    assert np.allclose(np.vstack(parts), ref_box, rtol=1e-12, atol=1e-12)

@@ -133,11 +133,27 @@ class MultiParametricQuadraticProgram(object):
         """
         x_buffer = [(np.zeros(self.f['x'].size), [])]
         crs_found = []
+        # The reference drops, before every step, the buffered points that a region found so far contains
+        # (parametric_programs.py:213-216: one `contains` per point and region, every time).  The set of regions only
+        # grows, so testing a point once, when its turn comes, against all regions found until then processes the same
+        # points in the same order; the rows of all regions are stacked so that the test is one matrix-vector product
+        # and a segmented max (same expression as Polyhedron.contains: max(A x - b) <= 1e-7).
+        p = self.f['x'].size
+        A_all, b_all, seg = np.zeros((0, p)), np.zeros(0), []
+
+        others = []   # regions that do not stack (equalities, no rows): tested one by one
+
+        def covered(x):
+            if any(cr.contains(x) for cr in others):
+                return True
+            if not seg:
+                return False
+            return bool((np.maximum.reduceat(A_all.dot(x) - b_all, seg) <= 1.e-7).any())
+
         while len(x_buffer) > 0:
-            x_buffer = [c for c in x_buffer if not any(cr.contains(c[0]) for cr in crs_found)]
-            if len(x_buffer) == 0:
-                break
             x, guess = x_buffer.pop(0)
+            if covered(x):
+                continue
             cr = self.explicit_solve_given_point(x, guess, verbose)
             if cr is None:
                 continue
@@ -147,6 +163,12 @@ class MultiParametricQuadraticProgram(object):
                 flipped = set(cr.active_set).symmetric_difference({i})
                 x_buffer.append((step, sorted(flipped)))
             crs_found.append(cr)
+            if cr.polyhedron.C.shape[0] == 0 and cr.polyhedron.A.shape[0] > 0:
+                seg.append(A_all.shape[0])
+                A_all = np.vstack((A_all, cr.polyhedron.A))
+                b_all = np.concatenate((b_all, cr.polyhedron.b))
+            else:
+                others.append(cr)
             if verbose:
                 print('CR found, active set: ' + str(cr.active_set) + '.')
         if verbose:

@@ -232,9 +232,12 @@ def test_mpqp_shapes_beyond_the_lds_image(oracle, n, m, p):
     assert np.array_equal(res.active_mask()[feas][~edge], ref["active"][feas][~edge])
 
 
-@pytest.mark.parametrize("n,m,p,scale", [(6, 40, 2, .6), (12, 150, 4, .5), (20, 300, 6, .4), (9, 90, 8, .5), (3, 20, 1, 1.5),
-                                         (30, 500, 3, .4)])
-def test_random_mpqps_shared_launch_vs_per_problem_kernel(n, m, p, scale):
+@pytest.mark.parametrize("n,m,p,scale,count", [(6, 40, 2, .6, 4000), (12, 150, 4, .5, 4000), (20, 300, 6, .4, 4000), (9, 90, 8, .5, 4000),
+                                               (3, 20, 1, 1.5, 4000), (30, 500, 3, .4, 4000),
+                                               # from 8192 states on the Gram-form kernel runs between the lane path and the
+                                               # Lawson-Hanson kernel: every column count it is compiled for (mp = 128 .. 512)
+                                               (9, 90, 8, .5, 12000), (12, 150, 4, .5, 12000), (20, 300, 6, .4, 10000), (8, 500, 2, .5, 9000)])
+def test_random_mpqps_shared_launch_vs_per_problem_kernel(n, m, p, scale, count):
     """Random strictly convex mpQPs of several shapes (every parameter count the screening pass is compiled for is
     close by): the shared-matrix launch (screening passes, closed-form first column, certificates) against the
     per-problem kernel on the same QPs.  Statuses and active sets identical, values to 1e-7."""
@@ -243,7 +246,7 @@ def test_random_mpqps_shared_launch_vs_per_problem_kernel(n, m, p, scale):
     L = rng.randn(n, n); Huu = L.dot(L.T) + n * np.eye(n)
     Hux = rng.randn(n, p); fu = rng.randn(n); fx = rng.randn(p)
     Au = rng.randn(m, n); Ax = rng.randn(m, p); b = np.abs(rng.randn(m)) * 3. + 1.
-    X = rng.randn(4000, p) * scale
+    X = rng.randn(count, p) * scale
     prep = PreparedMpqp(Huu, Hux, np.eye(p), fu, fx, .5, Au, Ax, b)
     res = prep.solve_batch(X, want_iters=True)
     again = prep.solve_batch(X, want_iters=True)      # certificate table from the first pass

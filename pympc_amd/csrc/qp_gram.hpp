@@ -15,10 +15,12 @@
 // Schur complement is small (nearly dependent rows), a coefficient is large or the residual small (near-infeasible:
 // the decision against the reference's threshold belongs to the factorised solve), or the iteration cap is reached.
 //
-// MI355X mapping.  Nothing of the 64 KB constraint matrix is touched, so the kernel needs no LDS beyond the column
-// norms (3 KB per workgroup) and ~100 VGPRs: 16 waves per CU hide the L2 round trips (one for the candidate's Gram
-// entries, one or two for the rows of the sweep) that bound an iteration.  Workgroups are persistent and draw
-// interleaved slices of states through an LDS ticket, as qp_solve_kernel does.
+// MI355X mapping.  Nothing of the 64 KB constraint matrix is touched, so the kernel needs no LDS beyond cn, m0, Gm and
+// the small objective tables (19 KB per workgroup for the cart-pole problem).  One persistent workgroup of 12 waves per
+// CU (3 per SIMD: at 168 VGPRs almost nothing spills; at 128 VGPRs / 16 waves the kernel moved 440 MB of scratch per
+// 1 M-state step through HBM); the waves draw interleaved slices of states through an LDS ticket, as qp_solve_kernel
+// does.  An iteration costs ~10 k cycles: one L2 round trip for the candidate's Gram entries, one per two rows of the
+// sweep, and ~700 wave instructions of k x k work in which at most 8 lanes are busy (change 9).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

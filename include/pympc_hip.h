@@ -43,6 +43,25 @@ int pympc_hip_abi_version(void);
 /* Text of the last error returned by an entry point on this thread. */
 const char *pympc_hip_last_error(void);
 
+/*
+ * Launch-policy knobs (no counterpart in the reference; for tests and for callers that tune a deployment).  They choose
+ * between kernels that implement the SAME method -- never what is computed -- so that every kernel can be driven at every
+ * size.  `value` < 0 only queries; `previous` (may be NULL) receives the value before the call.  Keys:
+ *   "lp_tile_min_rows" / "lp_tile_min_batch"   pympc_lp_solve_batch runs the eight-LPs-per-workgroup kernel from this many
+ *                                              rows / LPs against one shared matrix (defaults 2048 / 1024)
+ *   "gram_min_batch"     pympc_mpqp_solve_batch* runs the Gram-form kernel from this many states (default 8192).  NOTE:
+ *                        states with 3..8 active constraints are then finished by a different kernel than in a smaller
+ *                        batch: same method and decisions, values equal to rounding (1e-9), so argmin / min / multipliers
+ *                        of one state can differ in the last bits between a small and a large batch
+ *   "learn_min_batch"    certificate-learning pre-pass from this many states (default 131072)
+ *   "nnls_itmax_factor"  NNLS iteration limit = factor x columns (default 3 = scipy.optimize.nnls; 0 makes any problem
+ *                        that needs a column return PYMPC_MAXITER: how the tests reach that status)
+ *   "reserved_cus"       compute units the persistent launches leave free (default 0), for callers whose transfers run
+ *                        as copy kernels beside the solve
+ * Process-wide, read at launch time; not meant to be changed while other threads launch.
+ */
+int pympc_hip_tune(const char *key, long long value, long long *previous);
+
 /* Largest problem the wave-per-problem QP kernels accept: n <= *n_max variables, m <= *m_max rows. */
 void pympc_hip_limits(int *n_max, int *m_max);
 
@@ -96,6 +115,21 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
  */
 size_t pympc_mpqp_cuts_doubles(int p);
 int pympc_mpqp_cuts_reset(int p, double *cuts, void *stream);
+
+/*
+ * Certificates at set-up time (no counterpart in the reference).  The certificates of an mpQP are half-spaces that
+ * contain no feasible parameter: facets (or valid combinations of facets) of ONE polytope, the feasible set of
+ * parametric_programs.py:243-260 (get_feasible_set).  pympc_mpqp_cuts_learn solves the B sample states X [B x p] with
+ * the Lawson-Hanson kernel alone, writes nothing but status [B] (scratch) and appends the certificates of the infeasible
+ * ones to `cuts`; pympc_mpqp_cuts_mark declares the entries stored so far part of the prepared mpQP, and
+ * pympc_mpqp_cuts_restore drops everything learned since the mark (pympc_mpqp_cuts_reset still empties the table,
+ * mark included).  The host layer samples the bounding box of the feasible set at several scales right after
+ * pympc_mpqp_prepare, so that the first large batch starts with the table a long-running caller would have.
+ */
+int pympc_mpqp_cuts_learn(int n, int m, int p, const double *ws, double *cuts, const double *X, int64_t B, double tol,
+                          int32_t *status, void *stream);
+int pympc_mpqp_cuts_mark(int p, double *cuts, void *stream);
+int pympc_mpqp_cuts_restore(int p, double *cuts, void *stream);
 int pympc_mpqp_solve_batch_cuts(int n, int m, int p, const double *ws, double *cuts, const double *X, int64_t B, double tol,
                                 int n_out, double *argmin, double *vmin, double *mult, uint32_t *active, int32_t *status,
                                 int32_t *iters, void *stream);

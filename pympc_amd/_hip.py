@@ -22,12 +22,16 @@ _d = ctypes.c_double
 SIGNATURES = {
     "pympc_hip_abi_version": (_i, []),
     "pympc_hip_last_error": (ctypes.c_char_p, []),
+    "pympc_hip_tune": (_i, [ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "pympc_hip_limits": (None, [ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "pympc_mpqp_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i]),
     "pympc_mpqp_prepare": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pympc_mpqp_solve_batch": (_i, [_i, _i, _i, _vp, _vp, _i64, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pympc_mpqp_cuts_doubles": (ctypes.c_size_t, [_i]),
     "pympc_mpqp_cuts_reset": (_i, [_i, _vp, _vp]),
+    "pympc_mpqp_cuts_learn": (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _d, _vp, _vp]),
+    "pympc_mpqp_cuts_mark": (_i, [_i, _vp, _vp]),
+    "pympc_mpqp_cuts_restore": (_i, [_i, _vp, _vp]),
     "pympc_mpqp_solve_batch_cuts": (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pympc_mpqp_solve_batch_static": (_i, [_i, _i, _i, _vp, _vp, _i64, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pympc_nnls_workspace_doubles": (ctypes.c_size_t, [_i, _i, _i64]),
@@ -119,3 +123,28 @@ def lp_limits():
     m = _i(0)
     load_library().pympc_lp_limits(ctypes.byref(n), ctypes.byref(m))
     return n.value, m.value
+
+
+def tune(key, value=-1):
+    """pympc_hip_tune: set a launch-policy knob (value >= 0) and return its previous value; value < 0 only queries."""
+    prev = ctypes.c_longlong(0)
+    check(load_library().pympc_hip_tune(key.encode(), int(value), ctypes.byref(prev)))
+    return prev.value
+
+
+class tuned(object):
+    """Context manager: `with tuned(lp_tile_min_rows=1, lp_tile_min_batch=1): ...` restores the knobs on exit."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            self.old[k] = tune(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tune(k, v)
+        return False

@@ -83,14 +83,18 @@ __global__ void point_location_kernel(PlParams P)
     const int lane = tid & 63;
     double pbox_lo[PD], pbox_hi[PD];
     int prp0 = 0, prp1 = 0;
-    {
+#pragma unroll
+    for (int q = 0; q < PD; ++q) { pbox_lo[q] = 0.0; pbox_hi[q] = 0.0; }
+    if (P.nreg > 0) {   // (an empty table has no row ranges and no boxes to fetch: every point comes out uncovered)
         const int rl = min(lane, P.nreg - 1);
         prp0 = P.row_ptr[rl];
         prp1 = P.row_ptr[rl + 1];
+        if (P.box) {
 #pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            pbox_lo[q] = P.box ? P.box[(size_t)rl * 2 * PD + q] : 0.0;
-            pbox_hi[q] = P.box ? P.box[(size_t)rl * 2 * PD + PD + q] : 0.0;
+            for (int q = 0; q < PD; ++q) {
+                pbox_lo[q] = P.box[(size_t)rl * 2 * PD + q];
+                pbox_hi[q] = P.box[(size_t)rl * 2 * PD + PD + q];
+            }
         }
     }
     double xn[PD];
@@ -108,9 +112,14 @@ __global__ void point_location_kernel(PlParams P)
             for (int q = 0; q < PD; ++q) xn[q] = (nx < P.B) ? P.X[nx * PD + q] : 0.0;
         }
         int found = -1;
+        // a point with a NaN coordinate lies in no region (contains: max(A x - b) <= tol is False, polyhedron.py:596); the
+        // hull below is built from the other points (v_min / v_max drop NaN operands), so it must not inherit their region
+        bool xnum = true;
+#pragma unroll
+        for (int q = 0; q < PD; ++q) xnum = xnum && (x[q] == x[q]);
         // axis-aligned hull of the wave's points: a region whose box misses it holds none of them
         double wlo[PD], whi[PD];
-        constexpr bool kCorners = PD <= 3;   // hull-corner tests below: 2^p corners per row
+        constexpr bool kCorners = PD <= 4;   // hull-corner tests below: 2^p corners per row
         if (box || P.grid_masks || kCorners) {
 #pragma unroll
             for (int q = 0; q < PD; ++q) {
@@ -218,7 +227,7 @@ __global__ void point_location_kernel(PlParams P)
                     }
                     if (any_out) continue;
                     if (all_in) {
-                        if (inside) found = r;
+                        if (inside && xnum) found = r;
                         continue;
                     }
                 }

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 #include "../../include/pympc_hip.h"
@@ -48,7 +49,33 @@ int cu_count()
     return cached;
 }
 
+// workgroups of a persistent launch: one per compute unit, minus the units pympc_hip_tune("reserved_cus") keeps free
+// (for the copy kernels of a caller that overlaps transfers with the solve)
+int persistent_cus();
+
 constexpr size_t kLdsBytes = 160 * 1024;   // MI355X: 160 KiB LDS per CU, a single workgroup may own all of it
+
+// Launch-policy knobs (pympc_hip_tune): thresholds that pick between kernels of the same method, read at launch time.
+// They never change what is computed, only which kernel computes it (and, for nnls_itmax_factor, where the iteration
+// limit of scipy.optimize.nnls sits), so tests can drive every kernel at every size.
+struct Tune {
+    std::atomic<long long> lp_tile_min_rows{kLpTileMinRows};     // lp_tile_kernel from this many rows ...
+    std::atomic<long long> lp_tile_min_batch{kLpTileMinBatch};   // ... and this many LPs against one shared matrix
+    std::atomic<long long> gram_min_batch{8192};                 // mpqp_gram_kernel from this many states
+    std::atomic<long long> learn_min_batch{131072};              // certificate-learning pre-pass from this many states
+    std::atomic<long long> nnls_itmax_factor{3};                 // NNLS iteration limit = factor * columns (scipy: 3)
+    std::atomic<long long> reserved_cus{0};                      // compute units the persistent launches leave free
+};
+Tune g_tune;
+
+int persistent_cus()
+{
+    int ncu = cu_count();
+    if (ncu <= 0) ncu = 256;
+    const long long keep = g_tune.reserved_cus.load();
+    if (keep > 0 && keep < ncu) ncu -= (int)keep;
+    return ncu;
+}
 
 int check_launch(const char *what)
 {
@@ -157,7 +184,6 @@ int check_prep(const PrepGeom &G, int n, int m, int p)
 // at the same time as all the others.  The pre-pass writes no outputs: its statuses go to the head of the caller's
 // status array, which the main launch overwrites.  With a table that is already warm its infeasible states are
 // rejected at once and it costs one short launch.
-constexpr long long kLearnMinBatch = 131072;
 #ifndef PYMPC_LEARN_STATES
 #define PYMPC_LEARN_STATES 8192
 #endif
@@ -173,7 +199,8 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     P.wave_doubles = wave_lds_doubles(n, p, P.RP);
     const int mt = P.L.mp / 64;
     const size_t wave_bytes = (size_t)P.wave_doubles * 8;
-    if (shared && !learn_pass && P.cuts && p >= 1 && p <= kCutPMax && P.x_stride == p && P.B >= kLearnMinBatch) {
+    P.itmax_factor = (int)g_tune.nnls_itmax_factor.load();
+    if (shared && !learn_pass && P.cuts && p >= 1 && p <= kCutPMax && P.x_stride == p && P.B >= g_tune.learn_min_batch.load()) {
         SolveParams A = P;
         const long long step = P.B / kLearnStates;
         A.B = kLearnStates;
@@ -204,8 +231,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         // one persistent workgroup per CU over interleaved slices (qp_solve_kernel); slices of 8 problems once the batch
         // fills the chip (measured at 1M states with the screening pass ahead: 4 and 8 equal, 16 is 2 % and 32 is 5 % slower),
         // smaller ones below that so that every wave still has work
-        int ncu = cu_count();
-        if (ncu <= 0) ncu = 256;
+        int ncu = persistent_cus();
         chunk = learn_pass ? 1 : 8;
         while (chunk > 1 && P.B < chunk * nwaves * ncu) chunk >>= 1;
         const long long nslice = (P.B + chunk - 1) / chunk;
@@ -240,8 +266,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
             // Gram-form pass (qp_gram.hpp): what the lane path left pending and ends with up to kGramK active constraints
             // is finished here, without the matrix in LDS; the rest stays pending for the solve kernel below
             // (batches too small to keep the chip busy pay for its launch and staging more than it saves the solve kernel)
-            constexpr long long kGramMinBatch = 8192;
-            if (P.gram && !P.rhs && !P.raw && mt <= 8 && P.B >= kGramMinBatch) {
+            if (P.gram && !P.rhs && !P.raw && mt <= 8 && P.B >= g_tune.gram_min_batch.load()) {
                 SolveParams G = P;
                 int gslice = kGramSlice;   // states per ticket; smaller while the batch does not give every wave a slice
                 while (gslice > 1 && P.B < (long long)gslice * (kGramThreads / 64) * ncu) gslice >>= 1;
@@ -295,13 +320,45 @@ int scratch_address(double **out)
     return 0;
 }
 
+// table header: int32 count, lock, base (entries [0, base) were stored at set-up: pympc_mpqp_cuts_mark), spare
+__global__ void cuts_mark_kernel(double *cuts, int restore)
+{
+    int *hdr = reinterpret_cast<int *>(cuts);
+    if (threadIdx.x == 0) {
+        if (restore) { hdr[0] = min(hdr[0], hdr[2]); hdr[1] = 0; }
+        else hdr[2] = min(hdr[0], kCutMax);
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int pympc_hip_abi_version(void) { return 6; }   // 6: pympc_nnls_batch, pympc_pnnls_batch, pympc_mpqp_solve_batch_static
+int pympc_hip_abi_version(void) { return 7; }   // 7: pympc_hip_tune, pympc_mpqp_cuts_learn / _mark / _restore
 
 const char *pympc_hip_last_error(void) { return g_err; }
+
+int pympc_hip_tune(const char *key, long long value, long long *previous)
+{
+    if (!key) return fail(PYMPC_ERR_ARG, "pympc_hip_tune: null key");
+    struct { const char *name; std::atomic<long long> *slot; long long lo, hi; } knobs[] = {
+        {"lp_tile_min_rows", &g_tune.lp_tile_min_rows, 1, 1LL << 40},
+        {"lp_tile_min_batch", &g_tune.lp_tile_min_batch, 1, 1LL << 40},
+        {"gram_min_batch", &g_tune.gram_min_batch, 1, 1LL << 40},
+        {"learn_min_batch", &g_tune.learn_min_batch, 1, 1LL << 40},
+        {"nnls_itmax_factor", &g_tune.nnls_itmax_factor, 0, 1000},
+        {"reserved_cus", &g_tune.reserved_cus, 0, 128},
+    };
+    for (auto &k : knobs)
+        if (strcmp(key, k.name) == 0) {
+            if (previous) *previous = k.slot->load();
+            if (value < 0) return 0;   // query only
+            if (value < k.lo || value > k.hi) return fail(PYMPC_ERR_ARG, "pympc_hip_tune(%s): %lld outside [%lld, %lld]", key, value, k.lo, k.hi);
+            k.slot->store(value);
+            return 0;
+        }
+    return fail(PYMPC_ERR_ARG, "pympc_hip_tune: unknown key '%s'", key);
+}
 
 void pympc_hip_limits(int *n_max, int *m_max)
 {
@@ -355,6 +412,40 @@ int pympc_mpqp_cuts_reset(int p, double *cuts, void *stream)
     hipError_t e = hipMemsetAsync(cuts, 0, cut_table_doubles(p) * sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return fail(PYMPC_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     return 0;
+}
+
+int pympc_mpqp_cuts_mark(int p, double *cuts, void *stream)
+{
+    if (p < 1 || p > kCutPMax) return fail(PYMPC_ERR_UNSUPPORTED, "infeasibility cuts need 1 <= p <= %d parameters, got %d", kCutPMax, p);
+    if (!cuts) return fail(PYMPC_ERR_ARG, "pympc_mpqp_cuts_mark: null pointer");
+    hipLaunchKernelGGL(cuts_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cuts, 0);
+    return check_launch("cuts_mark_kernel");
+}
+
+int pympc_mpqp_cuts_restore(int p, double *cuts, void *stream)
+{
+    if (p < 1 || p > kCutPMax) return fail(PYMPC_ERR_UNSUPPORTED, "infeasibility cuts need 1 <= p <= %d parameters, got %d", kCutPMax, p);
+    if (!cuts) return fail(PYMPC_ERR_ARG, "pympc_mpqp_cuts_restore: null pointer");
+    hipLaunchKernelGGL(cuts_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cuts, 1);
+    return check_launch("cuts_mark_kernel");
+}
+
+int pympc_mpqp_cuts_learn(int n, int m, int p, const double *ws, double *cuts, const double *X, int64_t B, double tol,
+                          int32_t *status, void *stream)
+{
+    if (int rc = check_shape(n, m, p)) return rc;
+    if (p < 1 || p > kCutPMax) return fail(PYMPC_ERR_UNSUPPORTED, "infeasibility cuts need 1 <= p <= %d parameters, got %d", kCutPMax, p);
+    if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_mpqp_cuts_learn: negative batch size");
+    if (B == 0) return 0;
+    if (!ws || !cuts || !X || !status) return fail(PYMPC_ERR_ARG, "pympc_mpqp_cuts_learn: null pointer");
+    if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    SolveParams P;
+    memset(&P, 0, sizeof(P));
+    P.ws = ws; P.X = X; P.x_stride = p; P.B = B; P.tol = tol; P.status = status;
+    P.cuts = cuts;
+    P.gram = ws + ws_layout(n, m, p).total;
+    // the bare wave kernel (no screening, no outputs), one state per ticket: the launch shape of the learning pre-pass
+    return solve_common(true, n, m, p, P, (hipStream_t)stream, true);
 }
 
 int pympc_mpqp_solve_batch_cuts(int n, int m, int p, const double *ws, double *cuts, const double *X, int64_t B, double tol,
@@ -674,7 +765,7 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
     P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
     // many LPs against ONE large matrix and right-hand side (redundancy removal): one LP per wavefront, every loaded
     // row shared by the eight LPs of a workgroup (lp_tile.hpp)
-    if (a_stride == 0 && b_stride == 0 && n <= 8 && m >= kLpTileMinRows && B >= kLpTileMinBatch) {
+    if (a_stride == 0 && b_stride == 0 && n <= 8 && m >= g_tune.lp_tile_min_rows.load() && B >= g_tune.lp_tile_min_batch.load()) {
         const size_t lds_t = lp_tile_lds_doubles(n, m, P.RP) * 8;
         if (lds_t <= kLdsBytes) {
             int ncu = cu_count();

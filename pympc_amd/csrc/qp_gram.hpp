@@ -98,7 +98,7 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
 #pragma unroll
     for (int b = 0; b < kGramK; ++b) Hrow[b] = 0.0;
     double gam = 1.0, gz = 0.0, gtq = 0.0;
-    const int itmax = 3 * m;
+    const int itmax = P.itmax_factor * m;
     bool giveup = false;
 
     // z = H m_P, t, gam; returns the candidate coefficients -z gam (lanes < k)
@@ -142,7 +142,7 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
 
     for (;;) {
         // ---------------- the column of largest guaranteed decrease (the rule of qp_wave_solve), tested in Gram form
-        bool accepted = false;
+        bool accepted = false, stale = false;   // stale: gz / gtq / gam belong to a trial set whose new column was refused
         int j = -1, jl = 0, js = 0;
         double mj = 0.0, zt = 0.0;
         for (;;) {
@@ -171,7 +171,10 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
                 best = max_raw(best, kd);
             }
             const double gmax = wmax(best);
-            if (!(gmax > 0.0)) break;   // no column enters: optimal on the current passive set
+            if (!(gmax > 0.0)) {   // no column enters: optimal on the current passive set
+                if (stale) (void)gram_solve();   // ... whose solution the refused trials overwrote
+                break;
+            }
             if (k >= kGramK || k + 1 >= R || k + 1 >= m) { giveup = true; break; }
             j = 1023 - (int)(__double_as_longlong(gmax) & 0x3ffLL);
             jl = lane_of(j);
@@ -212,6 +215,7 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
             PYMPC_TICK(3)
             if (lane_f64(zt, k - 1) > 0.0) { accepted = true; break; }
             if (!gram_drop(k - 1)) { giveup = true; break; }
+            stale = true;
             if (lane == jl) {
 #pragma unroll
                 for (int s = 0; s < MT; ++s)

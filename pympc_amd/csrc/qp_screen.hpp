@@ -385,6 +385,8 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             }
         }
         // ---- finished here, handed to the wave kernel, or into queue 1
+        // (barrier: every wave has left the previous tile's queue loop, whose conditions read the counters pushed to below)
+        __syncthreads();
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const long long prob = base + (long long)s * NT + tid;
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             screen_push<1>(cand, &q_cnt[0], q1_id, q1_col, 0, (int)prob, c1);
         }
         __syncthreads();
-        while (q_cnt[0] >= NT) {   // (workgroup-uniform: the counters only change between barriers)
+        while (q_cnt[0] >= NT) {   // (workgroup-uniform: the counters only change between barriers; the next tile's pushes wait behind the barrier above)
             pass1(NT);
             if (q_cnt[1] >= NT) pass2(NT);
         }

@@ -64,6 +64,7 @@ struct SolveParams {
     int learn;                  // SHARED: this launch is the certificate-learning pre-pass (returns at once if the table is not empty)
     double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
     const double *gram;         // SHARED: Gram matrix of the constant rows [mp x mp] (ws_layout.hpp) or null
+    int itmax_factor;           // NNLS iteration limit = itmax_factor * columns (scipy.optimize.nnls: 3)
 };
 
 constexpr double kGramMaxCoeff = 1e3;   // first column through the Gram row only while its coefficient is moderate
@@ -292,7 +293,7 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
     int Pl = -1;        // lane l < k: column index at position l of the passive set
     double yl = 0.0;    // ... its coefficient
     double mPl = 0.0;   // ... its m(x) entry
-    const int itmax = 3 * m;
+    const int itmax = P.itmax_factor * m;
     bool qt_ready = false;
     // First column without a factorisation (shared mpQP with a Gram matrix): with the single passive column j the NNLS
     // solution is y = -m_j / (cn_j + m_j^2) and the squared residual cn_j / (cn_j + m_j^2); the next dual vector comes
@@ -618,11 +619,17 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
     extern __shared__ double lds[];
     constexpr int mp = 64 * MT;
     const int n = P.n, p = P.p;
-    // learning pre-pass: a table that already holds certificates (kept from an earlier call) needs none
-    if (SHARED && P.learn && P.cuts && cut_count(P.cuts) >= kCutLearnSkip) return;
     const SharedLds S_ = shared_lds(n, P.L);
     const size_t sharedD = SHARED ? S_.total : 0;
     int *ticket = reinterpret_cast<int *>(lds + sharedD);
+    // learning pre-pass: a table that already holds certificates (kept from an earlier call, or stored at prepare time)
+    // needs none.  Other workgroups of this launch append to the table meanwhile, so ONE thread reads the count and the
+    // whole workgroup branches on that value (every wave for itself could split the workgroup around the staging below).
+    if (SHARED && P.learn && P.cuts) {
+        if (threadIdx.x == 0) ticket[1] = cut_count(P.cuts) >= kCutLearnSkip ? 1 : 0;
+        __syncthreads();
+        if (ticket[1] != 0) return;
+    }
     double *waves = lds + sharedD + 2;
     const int wave = threadIdx.x >> 6;
     if (SHARED) {

@@ -131,11 +131,67 @@ class PreparedMpqp(object):
         # learned infeasibility certificates of this mpQP (include/pympc_hip.h: pympc_mpqp_solve_batch_cuts)
         nc = lib.pympc_mpqp_cuts_doubles(self.p)
         self.cuts = torch.zeros(nc, dtype=torch.float64, device=self.dev) if nc > 0 else None
+        self._seeded = False
 
-    def reset_cuts(self):
-        """Forget the infeasibility certificates learned so far (asynchronous on the current stream)."""
+    # batches from this size on seed the certificate table first (once per prepared mpQP); smaller ones learn as they go
+    SEED_MIN_BATCH = 65536
+    SEED_SCALES = (0.25, 0.4, 0.6, 0.85, 1.15, 1.6)
+    SEED_STATES = 4096
+
+    def feasible_box(self):
+        """Bounding box (lo, hi) of the feasible parameter set {x : exists u, Au u + Ax x <= b} (the polytope of
+        parametric_programs.py:243-260), by 2p LPs in (x, u) in one launch; None when it is empty, unbounded or beyond
+        the LP kernel's size."""
+        from .hip_lp import linear_program_batch
+        Au_, Ax_, b_ = self._inputs[5], self._inputs[6], self._inputs[7]
+        p, n = self.p, self.n
+        F = torch.zeros((2 * p, p + n), dtype=torch.float64, device=self.dev)
+        F[torch.arange(p), torch.arange(p)] = 1.
+        F[p + torch.arange(p), torch.arange(p)] = -1.
+        try:
+            res = linear_program_batch(F, torch.cat((Ax_, Au_), dim=1).contiguous(), b_, want_argmin=False,
+                                       want_mult=False, want_active=False)
+        except NotImplementedError:
+            return None
+        if not bool((res.t['status'] == _hip.OPTIMAL).all()):
+            return None
+        v = res.t['min']
+        return v[:p].clone(), -v[p:]
+
+    def seed_cuts(self, seed=0):
+        """Certificates at set-up time: solve sample states spread over the bounding box of the feasible set (several
+        scales, fixed seed: no user data involved) with the Lawson-Hanson kernel, keep the Farkas certificates of the
+        infeasible ones and mark them as part of the prepared mpQP.  Returns the number of certificates in the table."""
+        if self.cuts is None:
+            return 0
+        self._seeded = True
+        box = self.feasible_box()
+        if box is None:
+            return self.n_cuts()
+        lib = _hip.load_library()
+        lo, hi = box
+        c, h = .5 * (lo + hi), .5 * (hi - lo)
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        k = self.SEED_STATES
+        U = torch.rand((len(self.SEED_SCALES) * k, self.p), dtype=torch.float64, device=self.dev, generator=gen) * 2. - 1.
+        sc = torch.tensor(self.SEED_SCALES, dtype=torch.float64, device=self.dev).repeat_interleave(k)
+        X = (c[None, :] + sc[:, None] * h[None, :] * U).contiguous()
+        st = torch.empty(X.shape[0], dtype=torch.int32, device=self.dev)
+        _hip.check(lib.pympc_mpqp_cuts_learn(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(self.cuts), _hip.ptr(X),
+                                             X.shape[0], TOL, _hip.ptr(st), _hip.stream_ptr()))
+        _hip.check(lib.pympc_mpqp_cuts_mark(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
+        self._seed_keepalive = (X, st)
+        return self.n_cuts()
+
+    def reset_cuts(self, hard=False):
+        """Forget the infeasibility certificates learned from the batches solved so far; the ones stored at set-up time
+        (seed_cuts) stay.  hard=True empties the table altogether.  Asynchronous on the current stream."""
         if self.cuts is not None:
-            _hip.check(_hip.load_library().pympc_mpqp_cuts_reset(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
+            lib = _hip.load_library()
+            if hard:
+                _hip.check(lib.pympc_mpqp_cuts_reset(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
+            else:
+                _hip.check(lib.pympc_mpqp_cuts_restore(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
 
     def n_cuts(self):
         return 0 if self.cuts is None else int(self.cuts[:1].view(torch.int32)[0].item())
@@ -155,6 +211,8 @@ class PreparedMpqp(object):
         if out is None:
             out = _alloc_outputs(B, n_out, self.m, self.dev, want_mult, want_active, want_iters, want_min)
         cuts = self.cuts if use_cuts else None
+        if cuts is not None and not self._seeded and B >= self.SEED_MIN_BATCH:
+            self.seed_cuts()
         _hip.check(lib.pympc_mpqp_solve_batch_cuts(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(cuts), _hip.ptr(X), B,
                                                    float(tol), n_out, _hip.ptr(out['argmin']), _hip.ptr(out['min']),
                                                    _hip.ptr(out['multiplier_inequality']), _hip.ptr(out['active_bits']),

@@ -71,6 +71,39 @@ def test_cuts_reset_and_golden_c1():
     assert prep.n_cuts() > 0
 
 
+def test_certificates_stored_at_set_up():
+    """seed_cuts: certificates learned from samples of the feasible set's bounding box (no user data) are part of the
+    prepared mpQP: reset_cuts() returns to them, reset_cuts(hard=True) empties the table; they reject most infeasible
+    states of both benchmark distributions before any iteration, and never change a result."""
+    model, prep = _prep("c2_model.npz")
+    box = prep.feasible_box()
+    assert box is not None
+    lo, hi = (v.cpu().numpy() for v in box)
+    assert np.all(lo < 0) and np.all(hi > 0) and np.all(hi <= model["x_max"] + 1e-6) and np.all(lo >= -model["x_max"] - 1e-6)
+    n0 = prep.seed_cuts()
+    torch.cuda.synchronize()
+    assert 16 <= n0 <= 256
+    for scale in (0.3, 1.0):
+        X = np.random.RandomState(5).uniform(-scale * model["x_max"], scale * model["x_max"], (100000, 4))
+        plain = prep.solve_batch(X, use_cuts=False, want_iters=True)
+        prep.reset_cuts()
+        torch.cuda.synchronize()
+        assert prep.n_cuts() == n0
+        res = prep.solve_batch(X, use_cuts=True, want_iters=True)
+        torch.cuda.synchronize()
+        st = plain.numpy("status")
+        assert np.array_equal(res.numpy("status"), st)
+        for key in ("min", "argmin", "multiplier_inequality", "active_bits"):
+            assert np.array_equal(res.numpy(key), plain.numpy(key), equal_nan=True), key
+        hit = (st == 1) & (res.numpy("iters")[:, 0] == 0)
+        print("s = %.1f: %d set-up certificates reject %.1f %% of the infeasible states" % (scale, n0, 100. * hit.sum() / (st == 1).sum()))
+        assert hit.sum() >= 0.8 * (st == 1).sum()
+        assert prep.n_cuts() >= n0
+    prep.reset_cuts(hard=True)
+    torch.cuda.synchronize()
+    assert prep.n_cuts() == 0
+
+
 def test_cuts_disabled_without_parameters():
     """p = 0 or a null table: plain solve (quadratic_program_batch has no parameter space to cut)."""
     from pympc_amd import _hip

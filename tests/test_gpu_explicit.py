@@ -213,6 +213,88 @@ def test_full_size_grid_properties(nb):
     assert np.allclose(us[agree], res.numpy('argmin')[agree][:, :1], rtol=1e-6, atol=1e-6)
 
 
+def _oracle_locate_threaded(oracle, table, X, threads=16):
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = np.array_split(np.arange(len(X)), threads)
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda c: oracle.point_location(table, X[c]), chunks))
+    return tuple(np.concatenate([q[i] for q in parts]) for i in range(3))
+
+
+def _tie_mask(table, X, chunk=20000):
+    """Points whose max(Ax - b) sits within rounding (1e-12) of the 1e-7 tolerance in some region: either side is right."""
+    A, b, rp = table['A'], table['b'], table['row_ptr']
+    tie = np.zeros(len(X), bool)
+    for lo in range(0, len(X), chunk):
+        s = X[lo:lo + chunk].dot(A.T) - b
+        seg = np.maximum.reduceat(s, rp[:-1], axis=1)
+        tie[lo:lo + chunk] = (np.abs(seg - 1e-7) < 1e-12).any(axis=1)
+    return tie
+
+
+def test_full_size_grid_vs_oracle(nb, oracle):
+    """Config C4 at full size against the CPU oracle's linear scan (parametric_programs.py:442-463), index by index: on
+    the 3163 x 3163 grid nearly every wavefront's 64 points are neighbours, so this is where the hull-corner decisions of
+    point_location_kernel (all points of the wave inside / one row violated at every corner) decide almost everything;
+    random points (test_point_location_vs_oracle) never reach them."""
+    import torch
+    es = nb.explicit_solution
+    n = 3163
+    g = torch.linspace(-.5, .5, n, dtype=torch.float64, device='cuda')
+    Xd = torch.stack(torch.meshgrid(g, g, indexing='ij'), dim=-1).reshape(-1, 2).contiguous()
+    idx, u, V = es.locate(Xd, nu=1)
+    idx = idx.cpu().numpy(); u = u.cpu().numpy(); V = V.cpu().numpy()
+    X = Xd.cpu().numpy()
+    table = _table(es, 1)
+    ridx, ru, rV = _oracle_locate_threaded(oracle, table, X)
+    # a point whose max(Ax - b) sits within rounding (1e-12) of the 1e-7 tolerance in some region may fall either way:
+    # every disagreement must be such a point, and there must be few
+    mis = np.where(idx != ridx)[0]
+    print("10 M grid: %d points differ from the oracle (all must be 1e-12 ties of the tolerance), %.1f %% covered"
+          % (mis.size, 100. * (ridx >= 0).mean()))
+    assert mis.size <= 100
+    if mis.size:
+        assert _tie_mask(es.table(1), X[mis]).all()
+    ok = idx == ridx
+    cov = ok & (ridx >= 0)
+    assert cov.mean() > .3
+    assert np.allclose(u[cov], ru[cov], rtol=1e-9, atol=1e-9) and np.allclose(V[cov], rV[cov], rtol=1e-9, atol=1e-9)
+    unc = ok & (ridx < 0)
+    assert np.all(np.isnan(V[unc])) and np.all(np.isnan(u[unc]))
+
+
+def test_nan_points_and_empty_table(nb, oracle):
+    """A point with a NaN coordinate lies in no region (contains(): max(A x - b) <= tol is False, polyhedron.py:596),
+    also when the other 63 points of its wavefront all lie in one region (the hull-corner shortcut); a table without
+    regions leaves every point uncovered and reads nothing."""
+    import ctypes
+    import torch
+    from pympc_amd import _hip
+    es = nb.explicit_solution
+    # a tight cluster inside one region: the whole wavefront shares it
+    c = es.critical_regions[0].polyhedron.center
+    X = np.tile(c, (4096, 1)) + 1e-6 * np.random.RandomState(0).randn(4096, 2)
+    bad = np.arange(5, 4096, 37)
+    X[bad, bad % 2] = np.nan
+    idx, u, V = es.locate(X, nu=1)
+    idx = idx.cpu().numpy(); V = V.cpu().numpy(); u = u.cpu().numpy()
+    good = np.setdiff1d(np.arange(4096), bad)
+    ridx, ru, rV = oracle.point_location(_table(es, 1), X[good])
+    assert np.all(idx[bad] == -1) and np.all(np.isnan(V[bad])) and np.all(np.isnan(u[bad]))
+    assert np.array_equal(idx[good], ridx) and (ridx >= 0).all()
+    assert np.allclose(V[good], rV, rtol=1e-9, atol=1e-9)
+    # empty table through the C ABI
+    lib = _hip.load_library()
+    Xd = torch.as_tensor(np.random.RandomState(1).randn(1000, 2)).cuda()
+    oi = torch.zeros(1000, dtype=torch.int32, device='cuda'); ou = torch.zeros((1000, 1), dtype=torch.float64, device='cuda')
+    oV = torch.zeros(1000, dtype=torch.float64, device='cuda')
+    rp = torch.zeros(1, dtype=torch.int32, device='cuda')
+    _hip.check(lib.pympc_point_location(0, 0, 2, 1, None, None, _hip.ptr(rp), None, None, None, None, None, None, None, 0, None,
+                                        _hip.ptr(Xd), 1000, 1e-7, _hip.ptr(oi), _hip.ptr(ou), _hip.ptr(oV), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert bool((oi == -1).all()) and bool(torch.isnan(oV).all()) and bool(torch.isnan(ou).all())
+
+
 def test_table_is_reused_across_input_counts_and_boxes_come_in_chunks(nb, monkeypatch):
     """The look-up table's regions, boxes and cell grid do not depend on how many inputs are evaluated: asking for
     another nu rebuilds the laws only.  Bounding boxes of a table with more regions than one LP launch takes distinct

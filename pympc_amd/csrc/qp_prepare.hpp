@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64) qp_gram_kernel(int n, int mp, const double
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y;
     double acc = 0.0;
     for (int r = 0; r < n; ++r) acc = fma(Mt[(size_t)r * mp + i], Mt[(size_t)r * mp + j], acc);
-    Gr[(size_t)i * mp + j] = acc;
+    Gr[(size_t)i * mp + j] = (i == j) ? kGramDiag : acc;   // (the diagonal is never read as a norm: cn holds those)
 }
 
 }  // namespace pympc

@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "qp_wave.hpp"
 
 namespace pympc {
@@ -106,7 +108,11 @@ enum { kScreenDone = 0, kScreenNext = 1, kScreenPunt = 2 };
 
 // Stage K for the state of this lane (act: the lane holds an entry).  Returns kScreenDone (outputs written),
 // kScreenNext (jnext = column to add) or kScreenPunt (status set to pending).  Full wavefront: the sweep is wave-uniform.
-template <int PD, int K>
+// LAST: no stage follows (only "optimal here or not" is decided); U: columns per step of the sweep (their loads in flight
+// together: 8 while the passive set is small, fewer as K gathered entries per column fill the registers).
+// The diagonal of the Gram matrix holds kGramDiag instead of |M_j|^2 (qp_gram_kernel), so that the dual of a passive
+// column comes out hugely negative by itself: no per-column test for "is this one of mine".
+template <int PD, int K, bool LAST, int U>
 __device__ __forceinline__ int screen_stage(const SolveParams &P, cdouble_ptr m0, cdouble_ptr Gm, cdouble_ptr cn, cdouble_ptr tab,
                                             bool act, long long prob, const int (&cols)[K], int &jnext)
 {
@@ -188,51 +194,50 @@ __device__ __forceinline__ int screen_stage(const SolveParams &P, cdouble_ptr m0
     double best = -1.0;
     int jb = 0;
     const double ng = -gamma;
-    const double *grow[K];
+    unsigned cofs[K];
 #pragma unroll
-    for (int l = 0; l < K; ++l) grow[l] = P.gram + (act ? cols[l] : 0);   // Gr is symmetric: column c_l of row j
-    for (int j = 0; j < mp && __ballot(ok) != 0ull; j += 8) {
-        double mv[8], g[K][8];
+    for (int l = 0; l < K; ++l) cofs[l] = act ? (unsigned)cols[l] : 0u;   // Gr is symmetric: column c_l of row j
+    for (int j = 0; j < mp && __ballot(ok) != 0ull; j += U) {
+        double mv[U], g[K][U];
 #pragma unroll
-        for (int l = 0; l < K; ++l)
+        for (int u = 0; u < U; ++u) {
+            const double *grow = P.gram + (size_t)(j + u) * mp;   // (wave-uniform row, per-lane 32-bit column offset)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g[l][u] = grow[l][(size_t)(j + u) * mp];
+            for (int l = 0; l < K; ++l) g[l][u] = grow[cofs[l]];
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mv[u] = m0[j + u];
+        for (int u = 0; u < U; ++u) mv[u] = m0[j + u];
 #pragma unroll
         for (int q = 0; q < PD; ++q)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
-        double wv[8];
-        bool pos8 = false;
+            for (int u = 0; u < U; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+        double wv[U];
+        bool posU = false;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             double w = ng * mv[u];
 #pragma unroll
             for (int l = 0; l < K; ++l) w = fma(-y[l], g[l][u], w);
-            bool self = j + u >= m;
-#pragma unroll
-            for (int l = 0; l < K; ++l) self = self || (j + u == cols[l]);
-            wv[u] = self ? -1.0 : w;
-            pos8 = pos8 || (wv[u] > 0.0);
+            wv[u] = w;   // (pad columns: m = 1, Gr = 0: w = -gamma; passive columns: -y kGramDiag)
+            posU = posU || (w > 0.0);
         }
-        more = more || pos8;
-        if (K < kScreenStages && __ballot(ok && pos8) != 0ull) {   // (a last stage only needs to know whether a column enters)
+        more = more || posU;
+        if (!LAST && __ballot(ok && posU) != 0ull) {   // (a last stage only needs to know whether a column enters)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const double d = fma(mv[u], mv[u], cn[j + u]);
                 const double sc = (wv[u] > 0.0) ? wv[u] * wv[u] * __builtin_amdgcn_rcp(d) : -1.0;
                 if (sc > best) { best = sc; jb = j + u; }
             }
         }
-        if (K >= kScreenStages && __ballot(ok && !more) == 0ull) break;   // nobody left who could still be optimal
+        if (LAST && __ballot(ok && !more) == 0ull) break;   // nobody left who could still be optimal
     }
     if (!act) return kScreenDone;
     if (ok && !more) {
         screen_write<PD, K>(P, tab, prob, x, true, cols, lam, tq);
         return kScreenDone;
     }
-    if (ok && K < kScreenStages && best > 0.0) {
+    if (ok && !LAST && best > 0.0) {
         jnext = jb;
         return kScreenNext;
     }
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             const int id = q1_id[e];
             int cols[1] = {q1_col[e][0]};
             int jn = 0;
-            const int r = screen_stage<PD, 1>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
+            const int r = screen_stage<PD, 1, false, 8>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
             int c2[2] = {cols[0], jn};
             screen_push<2>(act && r == kScreenNext, &q_cnt[1], q2_id, q2_col, 0, id, c2);
         }
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             const int id = q2_id[e];
             int cols[2] = {q2_col[e][0], q2_col[e][1]};
             int jn = 0;
-            (void)screen_stage<PD, 2>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
+            (void)screen_stage<PD, 2, true, 8>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
         }
         __syncthreads();
         if (tid == 0) q_cnt[1] = cnt - take;

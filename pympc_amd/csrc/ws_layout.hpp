@@ -28,6 +28,7 @@ constexpr int kStatusInfeasible = 1;
 constexpr int kStatusMaxIter = 3;
 constexpr int kStatusNotPD = 4;
 constexpr int kStatusPending = -1;   // between the screening pass and the solve kernel only: never returned
+constexpr double kGramDiag = 1e300;  // diagonal of the stored Gram matrix (the true one is cn): see qp_screen.hpp
 
 constexpr int kNMax = 63;    // variables: R = n + 1 <= 64 rows, one lane per row
 constexpr int kPMax = 64;    // parameters: the parameter vector is staged one entry per lane

@@ -136,7 +136,8 @@ class PreparedMpqp(object):
     # batches from this size on seed the certificate table first (once per prepared mpQP); smaller ones learn as they go
     SEED_MIN_BATCH = 65536
     SEED_SCALES = (0.25, 0.4, 0.6, 0.85, 1.15, 1.6)
-    SEED_STATES = 4096
+    SEED_STATES = 131072       # per scale and round (>= the batch size from which a launch starts with a learning pre-pass)
+    SEED_ROUNDS = 2
 
     def feasible_box(self):
         """Bounding box (lo, hi) of the feasible parameter set {x : exists u, Au u + Ax x <= b} (the polytope of
@@ -159,9 +160,11 @@ class PreparedMpqp(object):
         return v[:p].clone(), -v[p:]
 
     def seed_cuts(self, seed=0):
-        """Certificates at set-up time: solve sample states spread over the bounding box of the feasible set (several
-        scales, fixed seed: no user data involved) with the Lawson-Hanson kernel, keep the Farkas certificates of the
-        infeasible ones and mark them as part of the prepared mpQP.  Returns the number of certificates in the table."""
+        """Certificates at set-up time.  Synthetic states spread over the bounding box of the feasible set (several
+        scales, fixed seed: no user data involved) are solved by the batched path itself, outputs discarded: states a
+        stored certificate already rejects cost nothing there, so every further batch spends its time on the part of
+        the infeasible region that is not covered yet.  The certificates found are marked as part of the prepared
+        mpQP (reset_cuts() returns to them).  Returns the number of certificates in the table."""
         if self.cuts is None:
             return 0
         self._seeded = True
@@ -173,14 +176,18 @@ class PreparedMpqp(object):
         c, h = .5 * (lo + hi), .5 * (hi - lo)
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         k = self.SEED_STATES
-        U = torch.rand((len(self.SEED_SCALES) * k, self.p), dtype=torch.float64, device=self.dev, generator=gen) * 2. - 1.
-        sc = torch.tensor(self.SEED_SCALES, dtype=torch.float64, device=self.dev).repeat_interleave(k)
-        X = (c[None, :] + sc[:, None] * h[None, :] * U).contiguous()
-        st = torch.empty(X.shape[0], dtype=torch.int32, device=self.dev)
-        _hip.check(lib.pympc_mpqp_cuts_learn(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(self.cuts), _hip.ptr(X),
-                                             X.shape[0], TOL, _hip.ptr(st), _hip.stream_ptr()))
+        st = torch.empty(k, dtype=torch.int32, device=self.dev)
+        keep = [st]
+        for rnd in range(self.SEED_ROUNDS):
+            for sc in self.SEED_SCALES:
+                U = torch.rand((k, self.p), dtype=torch.float64, device=self.dev, generator=gen) * 2. - 1.
+                X = (c[None, :] + sc * h[None, :] * U).contiguous()
+                keep.append(X)
+                _hip.check(lib.pympc_mpqp_solve_batch_cuts(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(self.cuts),
+                                                           _hip.ptr(X), k, TOL, 0, None, None, None, None, _hip.ptr(st), None,
+                                                           _hip.stream_ptr()))
         _hip.check(lib.pympc_mpqp_cuts_mark(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
-        self._seed_keepalive = (X, st)
+        self._seed_keepalive = keep
         return self.n_cuts()
 
     def reset_cuts(self, hard=False):

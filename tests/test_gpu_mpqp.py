@@ -161,7 +161,7 @@ def test_full_size_properties():
     full = prep.solve_batch(X[idx])
     assert np.array_equal(full.numpy("status"), r1.numpy("status")[idx])
     f = full.feasible
-    # (the 2000-state launch is below the batch size from which the Gram-form kernel runs, so states with 3 .. 8 active
+    # (a launch this size may be below the batch size from which the Gram-form kernel runs, so states with 3 .. 8 active
     # constraints are finished by different kernels in the two launches: same decisions, values to rounding)
     assert np.allclose(full.numpy("argmin")[f, 0], r1.numpy("argmin")[idx][f, 0], rtol=1e-9, atol=1e-9)
     assert np.array_equal(full.active_mask(), r1.active_mask()[idx])

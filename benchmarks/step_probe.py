@@ -19,11 +19,19 @@ B = 1000000
 model = dict(np.load(os.path.join(ROOT, "tests", "golden", "c2_model.npz")))
 prep = PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model["fx"], float(model["g"]),
                     model["Au"], model["Ax"], model["b"])
+if os.environ.get("PYMPC_SEED_KEEP"):
+    PreparedMpqp.SEED_KEEP = int(os.environ["PYMPC_SEED_KEEP"])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n0 = prep.seed_cuts()
+box = prep.feasible_box()
 torch.cuda.synchronize()
-print("seed_cuts: %d certificates in %.1f ms" % (n0, (time.perf_counter() - t0) * 1e3))
+print("feasible_box: %.1f ms" % ((time.perf_counter() - t0) * 1e3), [v.cpu().numpy().round(3).tolist() for v in box])
+t0 = time.perf_counter()
+PreparedMpqp.SEED_PROFILE = True
+n0 = prep.seed_cuts()
+print({k: round(v, 2) for k, v in prep.seed_timing.items()})
+torch.cuda.synchronize()
+print("seed_cuts: %d certificates in %.1f ms; they reject %.4f of the infeasible seed states" % (n0, (time.perf_counter() - t0) * 1e3, getattr(prep, "seed_coverage", float("nan"))))
 X = torch.as_tensor(np.random.RandomState(0).uniform(-scale * model["x_max"], scale * model["x_max"], (B, 4))).cuda()
 out = _alloc_outputs(B, 1, model["Au"].shape[0], X.device, want_mult=False, want_active=True, want_iters=True)
 BIG = 1 << 40

@@ -37,6 +37,13 @@
 namespace pympc {
 
 constexpr int kScreenThreads = 512;
+#ifndef PYMPC_SCREEN_U0
+#define PYMPC_SCREEN_U0 8
+#endif
+#ifndef PYMPC_SCREEN_U
+#define PYMPC_SCREEN_U 8
+#endif
+constexpr int kScreenU0 = PYMPC_SCREEN_U0;
 constexpr int kScreenStages = 2;          // lane-path stages after stage 0: states with up to this many active constraints
 constexpr double kScreenPivotMin = 1e-6;  // relative pivot of G below which the rows count as nearly dependent
 constexpr double kScreenGammaMin = 1e-8;  // squared residual below which the state counts as near-infeasible
@@ -268,6 +275,7 @@ template <int PD>
 __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams P)
 {
     constexpr int S = screen_states_per_lane<PD>();
+    constexpr int U0 = kScreenU0;   // columns per step of the stage-0 sweep
     constexpr int NT = kScreenThreads;
     constexpr int TILE = NT * S;
     static_assert(kScreenStages == 2, "queues below are written for two lane-path stages");
@@ -294,7 +302,7 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             const int id = q1_id[e];
             int cols[1] = {q1_col[e][0]};
             int jn = 0;
-            const int r = screen_stage<PD, 1, false, 8>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
+            const int r = screen_stage<PD, 1, false, PYMPC_SCREEN_U>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
             int c2[2] = {cols[0], jn};
             screen_push<2>(act && r == kScreenNext, &q_cnt[1], q2_id, q2_col, 0, id, c2);
         }
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             const int id = q2_id[e];
             int cols[2] = {q2_col[e][0], q2_col[e][1]};
             int jn = 0;
-            (void)screen_stage<PD, 2, true, 8>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
+            (void)screen_stage<PD, 2, true, PYMPC_SCREEN_U>(P, m0, Gm, cn, tab, act, (long long)id, cols, jn);
         }
         __syncthreads();
         if (tid == 0) q_cnt[1] = cnt - take;
@@ -345,42 +353,41 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             for (int q = 0; q < PD; ++q) dq[q] = cut[kCutHeader + (size_t)(q + 1) * kCutMax + c];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                double v = cc, a = fabs(cc);
+                double v = cc, a = fabs(cc);   // (fused: the margin is ten orders above the rounding either way)
 #pragma unroll
                 for (int q = 0; q < PD; ++q) {
-                    const double t = dq[q] * x[s][q];
-                    v += t;
-                    a += fabs(t);
+                    v = fma(dq[q], x[s][q], v);
+                    a = fma(fabs(dq[q]), fabs(x[s][q]), a);
                 }
                 hit[s] = hit[s] || (v < -kCutMargin * a);
             }
         }
         // ---- m(x): is some entry negative?  (a NaN state has none: the solve kernel also finds no column for it)
         // Along the way the column the NNLS would take first.
-        for (int j = 0; j < mp; j += 8) {
-            double c0[8], cg[PD][8];
+        for (int j = 0; j < mp; j += U0) {
+            double c0[U0], cg[PD][U0];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c0[u] = m0[j + u];
+            for (int u = 0; u < U0; ++u) c0[u] = m0[j + u];
 #pragma unroll
             for (int q = 0; q < PD; ++q)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) cg[q][u] = Gm[(size_t)q * mp + j + u];
+                for (int u = 0; u < U0; ++u) cg[q][u] = Gm[(size_t)q * mp + j + u];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                double mv[8];
+                double mv[U0];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) mv[u] = c0[u];
+                for (int u = 0; u < U0; ++u) mv[u] = c0[u];
 #pragma unroll
                 for (int q = 0; q < PD; ++q)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) mv[u] = fma(cg[q][u], x[s][q], mv[u]);
+                    for (int u = 0; u < U0; ++u) mv[u] = fma(cg[q][u], x[s][q], mv[u]);
                 bool neg8 = false;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) neg8 = neg8 || (mv[u] < 0.0);
+                for (int u = 0; u < U0; ++u) neg8 = neg8 || (mv[u] < 0.0);
                 neg[s] = neg[s] || neg8;
                 if (__ballot(neg8) != 0ull) {   // (most groups of columns have no negative entry in any lane)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < U0; ++u) {
                         const double wv = -mv[u];
                         const double d = fma(mv[u], mv[u], cn[j + u]);
                         const double sc = (wv > 0.0) ? wv * wv * __builtin_amdgcn_rcp(d) : -1.0;

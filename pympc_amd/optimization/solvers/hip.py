@@ -138,6 +138,7 @@ class PreparedMpqp(object):
     SEED_SCALES = (0.25, 0.4, 0.6, 0.85, 1.15, 1.6)
     SEED_STATES = 131072       # per scale and round (>= the batch size from which a launch starts with a learning pre-pass)
     SEED_ROUNDS = 2
+    SEED_PROFILE = False       # True: synchronise after every phase of seed_cuts and keep the times in self.seed_timing
 
     def feasible_box(self):
         """Bounding box (lo, hi) of the feasible parameter set {x : exists u, Au u + Ax x <= b} (the polytope of
@@ -168,7 +169,18 @@ class PreparedMpqp(object):
         if self.cuts is None:
             return 0
         self._seeded = True
+        import time
+        prof = self.SEED_PROFILE
+
+        def tick(label, t0):
+            if prof:
+                torch.cuda.synchronize()
+                self.seed_timing[label] = self.seed_timing.get(label, 0.) + (time.perf_counter() - t0) * 1e3
+            return time.perf_counter()
+        self.seed_timing = {}
+        t0 = time.perf_counter()
         box = self.feasible_box()
+        t0 = tick("feasible_box", t0)
         if box is None:
             return self.n_cuts()
         lib = _hip.load_library()
@@ -176,19 +188,64 @@ class PreparedMpqp(object):
         c, h = .5 * (lo + hi), .5 * (hi - lo)
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         k = self.SEED_STATES
-        st = torch.empty(k, dtype=torch.int32, device=self.dev)
-        keep = [st]
+        keep = []
         for rnd in range(self.SEED_ROUNDS):
             for sc in self.SEED_SCALES:
                 U = torch.rand((k, self.p), dtype=torch.float64, device=self.dev, generator=gen) * 2. - 1.
                 X = (c[None, :] + sc * h[None, :] * U).contiguous()
-                keep.append(X)
+                st = torch.empty(k, dtype=torch.int32, device=self.dev)
+                keep.append((X, st))
                 _hip.check(lib.pympc_mpqp_solve_batch_cuts(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(self.cuts),
                                                            _hip.ptr(X), k, TOL, 0, None, None, None, None, _hip.ptr(st), None,
                                                            _hip.stream_ptr()))
+                t0 = tick("batch scale %.2f" % sc, t0)
+        self._select_cuts(keep)
+        t0 = tick("selection", t0)
         _hip.check(lib.pympc_mpqp_cuts_mark(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
-        self._seed_keepalive = keep
         return self.n_cuts()
+
+    SEED_KEEP = 96            # certificates kept after set-up (every state of a batch is tested against all of them)
+    SEED_STRIDE = 16          # every SEED_STRIDE-th seed state takes part in the selection
+
+    def _select_cuts(self, batches):
+        """Keep the certificates that matter, most useful first.  The kernels test EVERY state against EVERY stored
+        certificate (p + 1 FMAs each), and sampling finds many that overlap.  Greedy cover on a subsample of the
+        infeasible seed states: repeatedly take the certificate that rejects most states no earlier pick rejects (the
+        kernels' own test: c + d'x below -1e-6 (|c| + |d|'|x|)), until SEED_KEEP are taken or nothing is gained.  What
+        the dropped ones covered is solved in full by the kernels, as before; no result depends on the table.  (On the
+        host with numpy: a ranking heuristic of a few milliseconds, not part of the solve path.)"""
+        n = self.n_cuts()
+        if n <= 1:
+            return
+        KC = 256                                                    # kCutMax (csrc/qp_wave.hpp)
+        body = self.cuts[2:2 + (self.p + 1) * KC].view(self.p + 1, KC)
+        tab = body[:, :n].cpu().numpy()
+        cc, D = tab[0], tab[1:]                                     # c [n], d [p x n]
+        k = self.SEED_STRIDE
+        Xs = torch.cat([x[::k] for x, _ in batches]).cpu().numpy()
+        ss = torch.cat([s_[::k] for _, s_ in batches]).cpu().numpy()
+        X = Xs[ss == _hip.INFEASIBLE]
+        if X.shape[0] == 0:
+            return
+        v = cc[None, :] + X.dot(D)
+        a = np.abs(cc)[None, :] + np.abs(X).dot(np.abs(D))
+        fires = v < -1e-6 * a                                        # [N x n]
+        total = fires.shape[0]
+        order = []
+        for _ in range(min(n, self.SEED_KEEP)):
+            gain = fires.sum(axis=0)
+            j = int(gain.argmax())
+            if gain[j] == 0:
+                break
+            order.append(j)
+            fires = fires[~fires[:, j]]                              # the states no pick rejects yet
+        if not order:
+            return
+        new = np.zeros((self.p + 1, KC))
+        new[:, :len(order)] = tab[:, order]
+        body.copy_(torch.as_tensor(new).to(self.dev))
+        self.cuts[:1].view(torch.int32)[0] = len(order)
+        self.seed_coverage = 1. - fires.shape[0] / float(total)      # of the infeasible seed states, by the kept certificates
 
     def reset_cuts(self, hard=False):
         """Forget the infeasibility certificates learned from the batches solved so far; the ones stored at set-up time

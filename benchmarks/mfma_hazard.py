@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Runs the v_mfma_f64_16x16x4_f64 read-after-write probe (pympc_amd/csrc/probes/mfma_f64_hazard.hip) with and without
-the wait-state pad of csrc/condense.hpp::mfma_f64_settle and prints one JSON line per variant."""
+the wait-state pad round 1 put behind every MFMA chain of csrc/condense.hpp and prints one JSON line per variant."""
 import ctypes
 import json
 import os

@@ -53,36 +53,30 @@ __device__ __forceinline__ cond_d4 mfma_f64(double a, double b, cond_d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// End of an MFMA chain: the accumulator is pinned to AGPRs and every later reader is ordered behind this point.
-// Round 1 had four `s_nop 15` here on the belief that hipcc 7.2's wait states between a v_mfma_f64_16x16x4_f64 and
-// its first non-MFMA reader were too few on gfx950.  The isolated probe (csrc/probes/mfma_f64_hazard.hip,
-// benchmarks/mfma_hazard.py, profiles/r02/mfma_hazard.jsonl) shows the compiler's own wait states are sufficient:
-// 3 x 4096 chains read back exactly with no pad.  What this kernel needs is the constraint itself: built with the
-// empty statement below all parity tests pass, built without any statement three of them fail (accumulator register 3
-// stale; -DPYMPC_NO_MFMA_SETTLE reproduces it).  So: no wait states (they cost ~9 k cycles per mode sequence), the
-// constraint stays, and tests/test_gpu_condense.py::test_mfma_f64_needs_no_wait_state_pad pins both findings.
-__device__ __forceinline__ void mfma_f64_settle(cond_d4 &acc)
-{
-#ifndef PYMPC_NO_MFMA_SETTLE
-    asm volatile("" : "+a"(acc));
-#else
-    (void)acc;
-#endif
-}
-
+// No wait states and no register constraints around the MFMA chains: the compiler's own hazard handling is correct for
+// straight-line code (csrc/probes/mfma_f64_hazard.hip: 3 x 4096 chains read back exactly).  What made rounds 1 and 2 add
+// pads and then an empty `asm volatile("" : "+a"(acc))` was a hazard at a CONTROL-FLOW JOIN (profiles/r03/mfma_settle_isa.txt):
+// with the column-tile count CT a run-time value the Gram loop was a chain of `if (I < CT) mfma`; the register allocator
+// kept acc[0] in VGPRs across iterations and bounced it through a[24:31]; the join behind the branch that skips the second
+// MFMA is reached either 13 wait states after the first MFMA (branch taken, CT == 1) or much later (fall-through), and
+// hipcc 7.2 sized the pad before the first v_accvgpr_read there (a31: the high half of accumulator element 3) for the
+// fall-through path only: s_nop 11 instead of the 17 it emits everywhere else.  Exactly the "element 3 stale, small
+// problems only" symptom of the three failing parity tests.  The empty asm only moved the allocation away from that
+// shape.  The fix is structural: CT is a template parameter, every loop over column tiles is unrolled at compile time
+// and no branch separates an MFMA from the first read of its accumulator.
 __device__ __forceinline__ void cond_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int KS>   // k-steps: ceil(nx / 4)
+template <int KS, int CT>   // k-steps: ceil(nx / 4); column tiles of S: ceil(W / 16)
 __global__ void __launch_bounds__(64) condense_kernel(CondParams P)
 {
     extern __shared__ double S[];   // [(N+1) nx][pitch]
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
     const long long prob = blockIdx.x;
-    const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, W = P.W, CT = P.CT, pitch = P.pitch;
+    const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, W = P.W, pitch = P.pitch;
     const int32_t *z = P.modes + prob * N;
 
     bool bad = false;
@@ -120,7 +114,6 @@ __global__ void __launch_bounds__(64) condense_kernel(CondParams P)
                 const double bv = kk < nx ? S[(t * nx + kk) * pitch + 16 * ct + li] : 0.0;
                 acc = mfma_f64(a[s], bv, acc);
             }
-            mfma_f64_settle(acc);
             const int col = 16 * ct + li;
 #pragma unroll
             for (int r = 0; r < KS; ++r) {
@@ -144,10 +137,11 @@ __global__ void __launch_bounds__(64) condense_kernel(CondParams P)
     // ---------------- cost: Gram = sum_t S_t' (Q_t S_t)   (controllers.py:716-731)
     double *Huu = P.Huu + (size_t)prob * n * n, *Hux = P.Hux + (size_t)prob * n * nx, *Hxx = P.Hxx + (size_t)prob * nx * nx;
     double *fu = P.fu + (size_t)prob * n, *fx = P.fx + (size_t)prob * nx;
+#pragma unroll 1
     for (int J = 0; J < CT; ++J) {
-        cond_d4 acc[kCondCtMax];
+        cond_d4 acc[CT];
 #pragma unroll
-        for (int I = 0; I < kCondCtMax; ++I) acc[I] = cond_d4{0.0, 0.0, 0.0, 0.0};
+        for (int I = 0; I < CT; ++I) acc[I] = cond_d4{0.0, 0.0, 0.0, 0.0};
         for (int t = 0; t <= N; ++t) {
             const double *Qt = (t == N) ? P.P : P.Q;
             cond_d4 qs = {0.0, 0.0, 0.0, 0.0};
@@ -158,26 +152,21 @@ __global__ void __launch_bounds__(64) condense_kernel(CondParams P)
                 const double bv = kk < nx ? S[(t * nx + kk) * pitch + 16 * J + li] : 0.0;
                 qs = mfma_f64(qa, bv, qs);
             }
-            mfma_f64_settle(qs);
             // register s of qs holds row (lane >> 4) + 4 s of Q_t S_t: the B operand of k-step s, in place
 #pragma unroll
-            for (int I = 0; I < kCondCtMax; ++I) {
-                if (I < CT) {
+            for (int I = 0; I < CT; ++I) {
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const int kk = 4 * s + lk;
-                        const double av = kk < nx ? S[(t * nx + kk) * pitch + 16 * I + li] : 0.0;
-                        acc[I] = mfma_f64(av, qs[s], acc[I]);
-                    }
+                for (int s = 0; s < KS; ++s) {
+                    const int kk = 4 * s + lk;
+                    const double av = kk < nx ? S[(t * nx + kk) * pitch + 16 * I + li] : 0.0;
+                    acc[I] = mfma_f64(av, qs[s], acc[I]);
                 }
             }
         }
         const int gj = 16 * J + li;
 #pragma unroll
-        for (int I = 0; I < kCondCtMax; ++I) mfma_f64_settle(acc[I]);
-#pragma unroll
-        for (int I = 0; I < kCondCtMax; ++I) {
-            if (I < CT) {
+        for (int I = 0; I < CT; ++I) {
+            {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int gi = 16 * I + lk + 4 * r;
@@ -223,8 +212,7 @@ __global__ void __launch_bounds__(64) condense_kernel(CondParams P)
                     const double bv = kk < nx ? S[(t * nx + kk) * pitch + 16 * ct + li] : 0.0;
                     acc = mfma_f64(a[s], bv, acc);
                 }
-                mfma_f64_settle(acc);
-                const int col = 16 * ct + li;
+                    const int col = 16 * ct + li;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * rt + lk + 4 * r;

@@ -704,15 +704,18 @@ int pympc_condense_batch(int nx, int nu, int N, int nm, int rmax, int rN, const 
     const size_t lds = (size_t)(N + 1) * nx * C.pitch * 8;
     if (lds > kLdsBytes) return fail(PYMPC_ERR_UNSUPPORTED, "prediction matrices (%zu B) do not fit the 160 KiB LDS", lds);
     hipStream_t st = (hipStream_t)stream;
-#define PYMPC_COND_CASE(KS)                                                                  \
-    case KS: {                                                                               \
-        if (int rc = allow_lds(condense_kernel<KS>, lds)) return rc;                         \
-        hipLaunchKernelGGL(condense_kernel<KS>, dim3((unsigned)B), dim3(64), lds, st, C);    \
-        break;                                                                               \
+#define PYMPC_COND_CASE(KS, CTV)                                                                  \
+    case 8 * KS + CTV: {                                                                          \
+        if (int rc = allow_lds(condense_kernel<KS, CTV>, lds)) return rc;                         \
+        hipLaunchKernelGGL((condense_kernel<KS, CTV>), dim3((unsigned)B), dim3(64), lds, st, C);  \
+        break;                                                                                    \
     }
-    switch ((nx + 3) / 4) {
-        PYMPC_COND_CASE(1) PYMPC_COND_CASE(2) PYMPC_COND_CASE(3) PYMPC_COND_CASE(4)
+#define PYMPC_COND_KS(KS) PYMPC_COND_CASE(KS, 1) PYMPC_COND_CASE(KS, 2) PYMPC_COND_CASE(KS, 3) PYMPC_COND_CASE(KS, 4) PYMPC_COND_CASE(KS, 5)
+    switch (8 * ((nx + 3) / 4) + C.CT) {
+        PYMPC_COND_KS(1) PYMPC_COND_KS(2) PYMPC_COND_KS(3) PYMPC_COND_KS(4)
+    default: return fail(PYMPC_ERR_UNSUPPORTED, "no condensing kernel for nx=%d, %d column tiles", nx, C.CT);
     }
+#undef PYMPC_COND_KS
 #undef PYMPC_COND_CASE
     return check_launch("condense_kernel");
 }

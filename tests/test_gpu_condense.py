@@ -219,8 +219,10 @@ def test_hybrid_bigM_vs_reference_golden():
 def test_mfma_f64_needs_no_wait_state_pad():
     """csrc/probes/mfma_f64_hazard.hip: chains of v_mfma_f64_16x16x4_f64 whose accumulator is stored immediately, with and
     without explicit wait states.  Both variants must be exact: the condensing kernel relies on the compiler's own
-    hazard handling (it only pins the accumulator, csrc/condense.hpp::mfma_f64_settle).  If the unpadded variant ever
-    returns a wrong entry, the wait states have to come back."""
+    hazard handling for straight-line MFMA chains (round 3: no pads, no register constraints; the wrong entries of
+    rounds 1 / 2 came from a branch between an MFMA and the read of its accumulator, csrc/condense.hpp header and
+    profiles/r03/mfma_settle_isa.txt, removed by making the column-tile count a template parameter).  If the unpadded
+    variant ever returns a wrong entry, the wait states have to come back."""
     import ctypes
     from pympc_amd.build import PROBE_PATH
     lib = ctypes.CDLL(PROBE_PATH)

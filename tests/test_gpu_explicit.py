@@ -263,6 +263,44 @@ def test_full_size_grid_vs_oracle(nb, oracle):
     assert np.all(np.isnan(V[unc])) and np.all(np.isnan(u[unc]))
 
 
+@pytest.mark.parametrize("p", [3, 4])
+def test_point_location_higher_dimensional_tables_vs_oracle(oracle, p):
+    """Tables with p = 3 and p = 4 parameters (the cart-pole controller of config C2 has p = 4): the hull-corner decisions
+    of point_location_kernel test 2^p corners per row.  Clusters of 64 neighbouring points (one wavefront each: the hull
+    is tiny, so nearly every region is decided by its corners) plus uniformly random points, against the oracle's scan."""
+    from pympc_amd.optimization.parametric_programs import MultiParametricQuadraticProgram
+    rng = np.random.RandomState(40 + p)
+    n, m = 4, 18
+    L = rng.randn(n, n)
+    H = {'uu': L.dot(L.T) + n * np.eye(n), 'ux': rng.randn(n, p), 'xx': np.eye(p)}
+    f = {'u': rng.randn(n), 'x': rng.randn(p)}
+    A = {'u': rng.randn(m, n), 'x': rng.randn(m, p)}
+    b = np.abs(rng.randn(m)) + 1.
+    # a box on the parameters keeps every critical region bounded (the table's bounding boxes need that)
+    A = {'u': np.vstack((A['u'], np.zeros((2 * p, n)))), 'x': np.vstack((A['x'], np.eye(p), -np.eye(p)))}
+    b = np.concatenate((b, 2. * np.ones(2 * p)))
+    mpqp = MultiParametricQuadraticProgram(H, f, .3, A, b)
+    es = mpqp.explicit_solve_from_samples(rng.uniform(-2., 2., (30000, p)))
+    assert len(es.critical_regions) >= 8
+    centres = rng.uniform(-1.9, 1.9, (4000, p))
+    X = (centres[:, None, :] + 2e-3 * rng.uniform(-1., 1., (4000, 64, p))).reshape(-1, p)
+    X = np.vstack((X, rng.uniform(-2.2, 2.2, (50000, p))))
+    idx, u, V = es.locate(X, nu=2)
+    idx = idx.cpu().numpy(); u = u.cpu().numpy(); V = V.cpu().numpy()
+    ridx, ru, rV = oracle.point_location(_table(es, 2), X)
+    mis = np.where(idx != ridx)[0]
+    assert mis.size <= 20
+    if mis.size:
+        assert _tie_mask(es.table(2), X[mis]).all()
+    ok = idx == ridx
+    cov = ok & (ridx >= 0)
+    assert cov.mean() > .2 and (ridx < 0).sum() > 100
+    assert np.allclose(u[cov], ru[cov], rtol=1e-9, atol=1e-9) and np.allclose(V[cov], rV[cov], rtol=1e-9, atol=1e-9)
+    # identical with every pruning device switched off (plain list scan)
+    c = es.locate(X, nu=2, use_boxes=False, use_grid=False)
+    assert np.array_equal(c[0].cpu().numpy(), idx)
+
+
 def test_nan_points_and_empty_table(nb, oracle):
     """A point with a NaN coordinate lies in no region (contains(): max(A x - b) <= tol is False, polyhedron.py:596),
     also when the other 63 points of its wavefront all lie in one region (the hull-corner shortcut); a table without

@@ -207,7 +207,7 @@ def main():
     if args.pcie_chunks > 0 and rank == 0:
         from pympc_amd.pipeline import FeedbackPipeline
         Xh = X.cpu().pin_memory()
-        pipe = FeedbackPipeline(prep, B, nu, depth=2, cold=(args.cuts == "cold"))
+        pipe = FeedbackPipeline(prep, B, nu, depth=3, cold=(args.cuts == "cold"), compute_streams=2)
         for t in range(max(40, args.warmup)):
             pipe.submit(Xh)
         torch.cuda.synchronize()
@@ -224,10 +224,11 @@ def main():
         per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         pcie = {"value": B * args.steps / dt, "unit": "QP solves/s", "ms_per_step": dt / max(args.steps, 1) * 1e3,
                 "median_ms_per_step": per[len(per) // 2] if per else None, "max_ms_per_step": per[-1] if per else None,
-                "device_buffer_sets": 2, "host_bytes_per_state": 8 * p + 8 * nu + 4, "streams": pipe.stream_report,
+                "device_buffer_sets": 3, "compute_streams": 2, "host_bytes_per_state": 8 * p + 8 * nu + 4, "streams": pipe.stream_report,
                 "note": "every step: pinned host states in, (u0, status) out to pinned host memory, certificate table "
                         "restored to its set-up state before the step's solve; transfers of neighbouring steps overlap the "
-                        "solve (pympc_amd/pipeline.py); 40 untimed steps first; one GPU (rank 0)"}
+                        "solve and the solves of consecutive steps alternate between two streams, each with its own "
+                        "certificate table (pympc_amd/pipeline.py); 40 untimed steps first; one GPU (rank 0)"}
 
     # roofline accounting: one extra untimed pass that also writes the iteration counters (deterministic kernel)
     if args.cuts == "cold":
@@ -261,6 +262,34 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         kept_ms = e0.elapsed_time(e1) / 5
+    # ... and with two steps in flight: consecutive steps alternate between two streams (own outputs, own copy of the
+    # certificate table), so that the tail of one step's kernels overlaps the head of the next step's.  A throughput
+    # figure for callers that have more than one batch at hand; `value` stays the one-stream number, whose kernel times
+    # the rocprofv3 summaries under profiles/ reproduce.
+    two = None
+    if use_cuts and rank == 0 and args.cuts == "cold":
+        from pympc_amd.pipeline import pick_streams
+        (s2,), rep2 = pick_streams(1)
+        strs = [torch.cuda.current_stream(), s2]
+        outs2 = [out, _alloc_outputs(B, nu, m, dev, want_mult=False, want_active=True, want_iters=False)]
+        tabs = [None, prep.clone_cuts()]
+        s2.wait_stream(strs[0])
+
+        def step2(t):
+            with torch.cuda.stream(strs[t % 2]):
+                prep.reset_cuts(table=tabs[t % 2])
+                prep.solve_batch(X, n_out=nu, out=outs2[t % 2], use_cuts=True, cuts_table=tabs[t % 2])
+        for t in range(6):
+            step2(t)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for t in range(args.steps):
+            step2(t)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        assert torch.equal(outs2[0]["status"], outs2[1]["status"]) and torch.equal(outs2[0]["active_bits"], outs2[1]["active_bits"])
+        two = {"value": B * args.steps / dt2, "unit": "QP solves/s", "ms_per_step": dt2 / max(args.steps, 1) * 1e3,
+               "independent_stream_found": rep2["independent"] == 1}
     F = algorithmic_flops(n, m, p, iters[:, 0], iters[:, 1])
     Fs = algorithmic_flops_strict(n, m, p, iters[:, 0], iters[:, 1])
     Fx = executed_flops(n, m, p, iters[:, 0], iters[:, 1])
@@ -298,7 +327,8 @@ def main():
                                               "warm": "table kept across steps", "off": "plain solve"}[args.cuts],
                        "certificates_from_set_up": n_seed, "certificates_after_a_step": n_cuts,
                        "states_rejected_by_a_cut": cut_hits,
-                       "plain_kernel_ms_without_cuts": plain_ms, "ms_per_step_with_kept_table": kept_ms},
+                       "plain_kernel_ms_without_cuts": plain_ms, "ms_per_step_with_kept_table": kept_ms,
+                       "two_steps_in_flight": two},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes of benchmarks/qp_launch.py (the "

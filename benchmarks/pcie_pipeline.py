@@ -106,22 +106,22 @@ def main():
                               median_step_ms=float(np.median(per)), steps_ms=[round(v, 2) for v in per],
                               feasible=int((sh[0] == 0).sum()))), flush=True)
 
-    def run_picked(name, depth, reserved=0):
+    def run_picked(name, depth, reserved=0, ncs=1):
         from pympc_amd.pipeline import FeedbackPipeline
         _hip.tune("reserved_cus", reserved)
         t0 = time.perf_counter()
-        pipe = FeedbackPipeline(prep, B, nu, depth=depth)
+        pipe = FeedbackPipeline(prep, B, nu, depth=depth, compute_streams=ncs)
         torch.cuda.synchronize()
         setup = time.perf_counter() - t0
-        for t in range(3):
+        for t in range(40):
             pipe.submit(Xh)
         torch.cuda.synchronize()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t1 = time.perf_counter()
-        marks[0].record(pipe.comp)
+        marks[0].record(pipe.comp[0])
         for t in range(args.steps):
             k = pipe.submit(Xh)
-            marks[t + 1].record(pipe.comp)
+            marks[t + 1].record(pipe.comp[0])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / args.steps
         per = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -135,6 +135,9 @@ def main():
         "picked": lambda: run_picked("picked", 2),
         "picked_reserved": lambda: run_picked("picked_reserved%d" % args.reserved, 2, reserved=args.reserved),
         "picked_depth3": lambda: run_picked("picked_depth3", 3),
+        "picked2c": lambda: run_picked("picked2c_depth2", 2, ncs=2),
+        "picked2c_depth3": lambda: run_picked("picked2c_depth3", 3, ncs=2),
+        "picked2c_depth4": lambda: run_picked("picked2c_depth4", 4, ncs=2),
         "serial": lambda: run("serial", 1, False),
         "streams3": lambda: run("streams3", 2, True),
         "streams3_hiprio": lambda: run("streams3_hiprio", 2, True, prio=-1),

@@ -247,21 +247,30 @@ class PreparedMpqp(object):
         self.cuts[:1].view(torch.int32)[0] = len(order)
         self.seed_coverage = 1. - fires.shape[0] / float(total)      # of the infeasible seed states, by the kept certificates
 
-    def reset_cuts(self, hard=False):
+    def reset_cuts(self, hard=False, table=None):
         """Forget the infeasibility certificates learned from the batches solved so far; the ones stored at set-up time
-        (seed_cuts) stay.  hard=True empties the table altogether.  Asynchronous on the current stream."""
-        if self.cuts is not None:
+        (seed_cuts) stay.  hard=True empties the table altogether.  Asynchronous on the current stream.  `table`: a copy
+        made by clone_cuts() instead of the prepared mpQP's own table."""
+        table = self.cuts if table is None else table
+        if table is not None:
             lib = _hip.load_library()
             if hard:
-                _hip.check(lib.pympc_mpqp_cuts_reset(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
+                _hip.check(lib.pympc_mpqp_cuts_reset(self.p, _hip.ptr(table), _hip.stream_ptr()))
             else:
-                _hip.check(lib.pympc_mpqp_cuts_restore(self.p, _hip.ptr(self.cuts), _hip.stream_ptr()))
+                _hip.check(lib.pympc_mpqp_cuts_restore(self.p, _hip.ptr(table), _hip.stream_ptr()))
+
+    def clone_cuts(self):
+        """A copy of the certificate table (set-up mark included) for launches that run CONCURRENTLY with others of this
+        mpQP on another stream: launches that share one table must be ordered on one stream (include/pympc_hip.h)."""
+        if self.cuts is not None and not self._seeded:
+            self.seed_cuts()
+        return None if self.cuts is None else self.cuts.clone()
 
     def n_cuts(self):
         return 0 if self.cuts is None else int(self.cuts[:1].view(torch.int32)[0].item())
 
     def solve_batch(self, X, tol=TOL, n_out=None, want_mult=True, want_active=True, want_iters=False, want_min=True,
-                    out=None, use_cuts=True):
+                    out=None, use_cuts=True, cuts_table=None):
         """X: [B x p] (numpy or device tensor).  Returns a BatchResult (device tensors, nothing synchronised).
 
         use_cuts: reject states that a stored Farkas certificate proves infeasible before iterating, and store the
@@ -274,8 +283,8 @@ class PreparedMpqp(object):
         n_out = self.n if n_out is None else n_out
         if out is None:
             out = _alloc_outputs(B, n_out, self.m, self.dev, want_mult, want_active, want_iters, want_min)
-        cuts = self.cuts if use_cuts else None
-        if cuts is not None and not self._seeded and B >= self.SEED_MIN_BATCH:
+        cuts = (self.cuts if cuts_table is None else cuts_table) if use_cuts else None
+        if cuts is not None and cuts_table is None and not self._seeded and B >= self.SEED_MIN_BATCH:
             self.seed_cuts()
         _hip.check(lib.pympc_mpqp_solve_batch_cuts(self.n, self.m, self.p, _hip.ptr(self.ws), _hip.ptr(cuts), _hip.ptr(X), B,
                                                    float(tol), n_out, _hip.ptr(out['argmin']), _hip.ptr(out['min']),

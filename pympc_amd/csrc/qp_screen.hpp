@@ -38,10 +38,13 @@ namespace pympc {
 
 constexpr int kScreenThreads = 512;
 #ifndef PYMPC_SCREEN_U0
-#define PYMPC_SCREEN_U0 8
+#define PYMPC_SCREEN_U0 2
 #endif
 #ifndef PYMPC_SCREEN_U
-#define PYMPC_SCREEN_U 8
+#define PYMPC_SCREEN_U 4
+#endif
+#ifndef PYMPC_SCREEN_KEY0
+#define PYMPC_SCREEN_KEY0 0
 #endif
 constexpr int kScreenU0 = PYMPC_SCREEN_U0;
 constexpr int kScreenStages = 2;          // lane-path stages after stage 0: states with up to this many active constraints
@@ -196,49 +199,53 @@ __device__ __forceinline__ int screen_stage(const SolveParams &P, cdouble_ptr m0
             ok = ok && (lam[l] > 0.0) && (y[l] < kGramMaxCoeff);
         }
     }
-    // ---- next dual vector over all columns; the best entering column along the way
+    // ---- next dual vector over all columns; the best entering column along the way.
+    // Straight-line code per column: the score w^2 / (cn + m^2) is compared through s = w rsq(cn + m^2) (same order for
+    // w > 0, negative otherwise) with the column index packed into the low 11 mantissa bits (2047 - j: lowest index among
+    // scores equal to 2^-41 relative), so that ONE v_max_f64 per column keeps the arg-max; a last stage only keeps max w.
     bool more = false;
-    double best = -1.0;
     int jb = 0;
-    const double ng = -gamma;
-    unsigned cofs[K];
+    {
+        const double ng = -gamma;
+        unsigned boff[K];
 #pragma unroll
-    for (int l = 0; l < K; ++l) cofs[l] = act ? (unsigned)cols[l] : 0u;   // Gr is symmetric: column c_l of row j
-    for (int j = 0; j < mp && __ballot(ok) != 0ull; j += U) {
-        double mv[U], g[K][U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double *grow = P.gram + (size_t)(j + u) * mp;   // (wave-uniform row, per-lane 32-bit column offset)
-#pragma unroll
-            for (int l = 0; l < K; ++l) g[l][u] = grow[cofs[l]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) mv[u] = m0[j + u];
-#pragma unroll
-        for (int q = 0; q < PD; ++q)
-#pragma unroll
-            for (int u = 0; u < U; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
-        double wv[U];
-        bool posU = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            double w = ng * mv[u];
-#pragma unroll
-            for (int l = 0; l < K; ++l) w = fma(-y[l], g[l][u], w);
-            wv[u] = w;   // (pad columns: m = 1, Gr = 0: w = -gamma; passive columns: -y kGramDiag)
-            posU = posU || (w > 0.0);
-        }
-        more = more || posU;
-        if (!LAST && __ballot(ok && posU) != 0ull) {   // (a last stage only needs to know whether a column enters)
+        for (int l = 0; l < K; ++l) boff[l] = act ? 8u * (unsigned)cols[l] : 0u;   // Gr is symmetric: column c_l of row j
+        const char *gbase = reinterpret_cast<const char *>(P.gram);
+        double bestkey = 0.0, wtop = -1.0;
+        for (int j = 0; j < mp && __ballot(ok) != 0ull; j += U) {
+            double mv[U], g[K][U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double d = fma(mv[u], mv[u], cn[j + u]);
-                const double sc = (wv[u] > 0.0) ? wv[u] * wv[u] * __builtin_amdgcn_rcp(d) : -1.0;
-                if (sc > best) { best = sc; jb = j + u; }
+                const char *grow = gbase + (size_t)(j + u) * mp * sizeof(double);   // (wave-uniform row + per-lane 32-bit byte offset)
+#pragma unroll
+                for (int l = 0; l < K; ++l) g[l][u] = *reinterpret_cast<const double *>(grow + boff[l]);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) mv[u] = m0[j + u];
+#pragma unroll
+            for (int q = 0; q < PD; ++q)
+#pragma unroll
+                for (int u = 0; u < U; ++u) mv[u] = fma(Gm[(size_t)q * mp + j + u], x[q], mv[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double w = ng * mv[u];   // (pad columns: m = 1, Gr = 0: w = -gamma; passive columns: -y kGramDiag)
+#pragma unroll
+                for (int l = 0; l < K; ++l) w = fma(-y[l], g[l][u], w);
+                if (LAST) {
+                    wtop = max_raw(wtop, w);
+                } else {
+                    const double d = fma(mv[u], mv[u], cn[j + u]);
+                    const double sc = w * __builtin_amdgcn_rsq(d);
+                    const long long key = (__double_as_longlong(sc) & ~0x7ffLL) | (long long)(2047 - (j + u));
+                    bestkey = max_raw(bestkey, __longlong_as_double(key));
+                }
+            }
+            if (LAST && __ballot(ok && !(wtop > 0.0)) == 0ull) break;   // nobody left who could still be optimal
         }
-        if (LAST && __ballot(ok && !more) == 0ull) break;   // nobody left who could still be optimal
+        more = LAST ? (wtop > 0.0) : (bestkey > 0.0);
+        jb = 2047 - (int)(__double_as_longlong(bestkey) & 0x7ffLL);
     }
+    const double best = more ? 1.0 : -1.0;
     if (!act) return kScreenDone;
     if (ok && !more) {
         screen_write<PD, K>(P, tab, prob, x, true, cols, lam, tq);
@@ -342,7 +349,7 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
             for (int q = 0; q < PD; ++q) x[s][q] = valid[s] ? P.X[prob * P.x_stride + q] : 0.0;
             hit[s] = false;
             neg[s] = false;
-            best[s] = -1.0;
+            best[s] = 0.0;
             jb[s] = 0;
         }
         // ---- stored certificates (same test as cut_fires)
@@ -381,6 +388,16 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
                 for (int q = 0; q < PD; ++q)
 #pragma unroll
                     for (int u = 0; u < U0; ++u) mv[u] = fma(cg[q][u], x[s][q], mv[u]);
+#if PYMPC_SCREEN_KEY0
+                // straight-line arg-max as in screen_stage: s = -m rsq(cn + m^2) with the column packed into its low bits
+#pragma unroll
+                for (int u = 0; u < U0; ++u) {
+                    const double d = fma(mv[u], mv[u], cn[j + u]);
+                    const double sc = -mv[u] * __builtin_amdgcn_rsq(d);
+                    const long long key = (__double_as_longlong(sc) & ~0x7ffLL) | (long long)(2047 - (j + u));
+                    best[s] = max_raw(best[s], __longlong_as_double(key));
+                }
+#else
                 bool neg8 = false;
 #pragma unroll
                 for (int u = 0; u < U0; ++u) neg8 = neg8 || (mv[u] < 0.0);
@@ -388,13 +405,19 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
                 if (__ballot(neg8) != 0ull) {   // (most groups of columns have no negative entry in any lane)
 #pragma unroll
                     for (int u = 0; u < U0; ++u) {
-                        const double wv = -mv[u];
                         const double d = fma(mv[u], mv[u], cn[j + u]);
-                        const double sc = (wv > 0.0) ? wv * wv * __builtin_amdgcn_rcp(d) : -1.0;
-                        if (sc > best[s]) { best[s] = sc; jb[s] = j + u; }
+                        const double sc = -mv[u] * __builtin_amdgcn_rsq(d);
+                        const long long key = (__double_as_longlong(sc) & ~0x7ffLL) | (long long)(2047 - (j + u));
+                        best[s] = max_raw(best[s], __longlong_as_double(key));
                     }
                 }
+#endif
             }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            neg[s] = best[s] > 0.0;   // some m_j(x) < 0 (a NaN state has none: the solve kernel also finds no column for it)
+            jb[s] = 2047 - (int)(__double_as_longlong(best[s]) & 0x7ffLL);
         }
         // ---- finished here, handed to the wave kernel, or into queue 1
         // (barrier: every wave has left the previous tile's queue loop, whose conditions read the counters pushed to below)

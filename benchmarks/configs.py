@@ -71,23 +71,33 @@ def c1():
 
 
 def c2pcie():
+    """Host-to-host rate of C2 through pympc_amd.pipeline.FeedbackPipeline (the figure bench.py reports as pcie_inclusive)."""
+    from pympc_amd.pipeline import FeedbackPipeline
     g = golden("c2_model")
     ctrl = controller(g)
+    prep = ctrl.mpqp.prepared()
+    prep.seed_cuts()
     B = 1000000
     x_max = g["x_max"]
     Xh = torch.as_tensor(np.random.RandomState(0).uniform(-.3 * x_max, .3 * x_max, (B, 4))).pin_memory()
-    uh = torch.empty((B, 1), dtype=torch.float64).pin_memory(); sh = torch.empty(B, dtype=torch.int32).pin_memory()
-
-    def step():
-        Xd = Xh.cuda(non_blocking=True)
-        res = ctrl.feedback_batch(Xd)
-        uh.copy_(res.t['argmin'], non_blocking=True); sh.copy_(res.t['status'], non_blocking=True)
-    t = gpu_time(step, reps=5, warmup=2)
+    out = {}
+    for ncs, depth in ((1, 2), (2, 3)):
+        pipe = FeedbackPipeline(prep, B, 1, depth=depth, compute_streams=ncs)
+        for _ in range(40):
+            pipe.submit(Xh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            k = pipe.submit(Xh)
+        torch.cuda.synchronize()
+        out[ncs] = (time.perf_counter() - t0) / 20
+        pipe.wait(k)
     Xd = Xh.cuda()
-    t_res = gpu_time(lambda: ctrl.feedback_batch(Xd), reps=5, warmup=1)
-    return dict(config="C2-pcie", workload="C2 (cart-pole N=20, 1M states, s=0.3): pinned host states -> HBM, solve, (u0, status) -> pinned host",
-                value=B / t, unit="QP solves/s", ms=t * 1e3, ms_resident=t_res * 1e3, resident_value=B / t_res,
-                note="PCIe-inclusive rate; never the headline value")
+    t_res = gpu_time(lambda: (prep.reset_cuts(), ctrl.feedback_batch(Xd)), reps=5, warmup=1)
+    return dict(config="C2-pcie", workload="C2 (cart-pole N=20, 1M states, s=0.3): pinned host states -> HBM, solve, (u0, status) -> pinned host; "
+                                           "transfers overlapped with the solves of neighbouring batches (pympc_amd/pipeline.py)",
+                value=B / out[2], unit="QP solves/s", ms_two_compute_streams=out[2] * 1e3, ms_one_compute_stream=out[1] * 1e3,
+                ms_resident=t_res * 1e3, resident_value=B / t_res, note="PCIe-inclusive rate; never the headline value")
 
 
 def c2setup():
@@ -180,6 +190,24 @@ def c4():
                 cpu_baseline=dict(value=len(sample) / t_cpu, unit="points/s", cores=1, kind="port", sample="every 50th grid point (%d)" % len(sample)))
 
 
+def _c5_roofline(n, m, p, B, in_bytes, it, t):
+    """qp_prepare_kernel + qp_solve_kernel<4, false> of one pympc_mpqp_multi_solve call.  HBM side: every sequence's
+    matrices are read once (what the condensing kernel wrote), its factorised workspace is written once and read once by
+    the solve (Mt, m0, Gm, cn and the small tables; T is skipped for a costs-only call), outputs are 12 B.  Flop side:
+    Cholesky / inverses / M = A L^-T of the prepare (n^3 + 2 m n^2 + 2 m n p) plus the SURVEY 8(d) active-set count on
+    the kernel's iteration counters."""
+    sys.path.insert(0, ROOT)
+    from bench import algorithmic_flops
+    mp = 64 * next(b for b in (2, 4, 6, 8, 12, 16, 24, 32) if (m + 63) // 64 <= b)
+    ws = 8 * ((n + p + 2) * mp + n + n * p + p * p + p + 1)
+    bytes_ = B * (in_bytes + 2 * ws + 12)
+    flops = B * (n ** 3 + 2. * m * n * n + 2. * m * n * p) + float(algorithmic_flops(n, m, p, it[:, 0], it[:, 1]).sum())
+    return dict(kernels="qp_prepare_kernel + qp_solve_kernel<4, false>", bound="hbm", achieved=bytes_ / t / 1e9, peak=PEAK_HBM, unit="GB/s",
+                frac=bytes_ / t / 1e9 / PEAK_HBM, algorithmic_bytes_per_launch=bytes_, algorithmic_tflops=flops / t / 1e12,
+                frac_fp64_valu=flops / t / 1e12 / PEAK_F64,
+                note="time = the whole call (both kernels; rocprofv3 split in profiles/r03/kernel_stats_configs.csv)")
+
+
 def c5():
     from oracle import oracle as O
     from pympc_amd.control.controllers import HybridModelPredictiveController
@@ -220,8 +248,9 @@ def c5():
                 value=B / (t_cond + t_solve), unit="mode-sequence QPs/s (condense + prepare + solve)", ms_condense=t_cond * 1e3,
                 ms_prepare_and_solve=t_solve * 1e3, feasible=int(feas.sum()), best_sequence=[int(z) for z in sq[kbest]], best_cost=float(V[kbest]),
                 mean_outer_iterations=float(it[:, 0].mean()), sample_parity_vs_oracle="%d/200" % agree,
-                roofline=dict(kernel="condense_kernel<1>", bound="hbm", achieved=B * out_bytes / t_cond / 1e9, peak=PEAK_HBM, unit="GB/s",
+                roofline=dict(kernel="condense_kernel<1, 1>", bound="hbm", achieved=B * out_bytes / t_cond / 1e9, peak=PEAK_HBM, unit="GB/s",
                               frac=B * out_bytes / t_cond / 1e9 / PEAK_HBM, algorithmic_bytes_per_launch=B * out_bytes),
+                roofline_prepare_and_solve=_c5_roofline(n, m, p, B, out_bytes, it, t_solve),
                 cpu_baseline=dict(value=200 / t_cpu, unit="mode-sequence QPs/s", cores=1, kind="port", sample="200 random sequences: oracle_condense + oracle_qp"))
 
 

@@ -6,8 +6,10 @@ the states and the download of the results), for timing variants of the pipeline
     rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/pcie -- \
         python3 benchmarks/pcie_pipeline.py --variant streams3 --steps 6    # one variant under the tracer
 
-Variants: serial (one stream), streams3 (bench.py's: upload / solve / download streams, two buffer sets),
-streams3+reserved (persistent launches leave CUs free for copy kernels), chunked uploads.
+Variants: picked* (pympc_amd.pipeline.FeedbackPipeline: streams chosen by measurement; 2c = two compute streams), serial
+(one stream), streams3 (round 2's: upload / solve / download on whatever streams torch hands out), streams3+reserved
+(persistent launches leave CUs free for copy kernels), chunked uploads.  High-priority copy streams were tried once and
+hung the run (the second variant never finished): not offered.
 """
 import argparse
 import json
@@ -45,15 +47,15 @@ def main():
     B = args.batch
     Xh = torch.as_tensor(np.random.RandomState(0).uniform(-args.scale * x_max, args.scale * x_max, (B, p))).pin_memory()
 
-    def run(name, nbuf, streams, reserved=0, up_chunks=1, steps=args.steps, prio=0):
+    def run(name, nbuf, streams, reserved=0, up_chunks=1, steps=args.steps):
         _hip.tune("reserved_cus", reserved)
         uh = [torch.empty((B, nu), dtype=torch.float64).pin_memory() for _ in range(nbuf)]
         sh = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
         Xd = [torch.empty((B, p), dtype=torch.float64, device=dev) for _ in range(nbuf)]
         outs = [_alloc_outputs(B, nu, m, dev, want_mult=False, want_active=True, want_iters=False) for _ in range(nbuf)]
         comp = torch.cuda.current_stream()
-        s_in = torch.cuda.Stream(priority=prio) if streams else comp
-        s_out = torch.cuda.Stream(priority=prio) if streams else comp
+        s_in = torch.cuda.Stream() if streams else comp
+        s_out = torch.cuda.Stream() if streams else comp
         ev_in = [torch.cuda.Event() for _ in range(nbuf)]
         ev_done = [torch.cuda.Event() for _ in range(nbuf)]
         ev_out = [torch.cuda.Event() for _ in range(nbuf)]
@@ -140,8 +142,6 @@ def main():
         "picked2c_depth4": lambda: run_picked("picked2c_depth4", 4, ncs=2),
         "serial": lambda: run("serial", 1, False),
         "streams3": lambda: run("streams3", 2, True),
-        "streams3_hiprio": lambda: run("streams3_hiprio", 2, True, prio=-1),
-        "streams3_hiprio_buf3": lambda: run("streams3_hiprio_buf3", 3, True, prio=-1),
         "streams3_buf3": lambda: run("streams3_buf3", 3, True),
         "streams3_reserved": lambda: run("streams3_reserved%d" % args.reserved, 2, True, reserved=args.reserved),
         "streams3_reserved_buf3": lambda: run("streams3_reserved%d_buf3" % args.reserved, 3, True, reserved=args.reserved),

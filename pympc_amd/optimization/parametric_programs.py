@@ -330,7 +330,8 @@ class ExplicitSolution(object):
         t['grid'] = self._cell_grid(t, tol=1.e-7)
         if t['grid'] is not None:
             t['dev']['grid_geom'] = _hip.to_device(t['grid']['geom'])
-            t['dev']['grid_masks'] = torch.as_tensor(t['grid']['masks'].view(np.int64)).to(_hip.device())
+            t['dev']['grid_masks'] = t['grid']['masks']
+            t['dev']['grid_sure'] = t['grid']['sure']
         self._table = t
         return t
 
@@ -378,16 +379,22 @@ class ExplicitSolution(object):
         box[:, p:] = hi + pad * (1. + np.abs(hi))
         return box
 
-    GRID_CELLS_PER_AXIS = {1: 4096, 2: 128, 3: 32, 4: 12}
+    GRID_CELLS_PER_AXIS = {1: 4096, 2: 256, 3: 32, 4: 12}
 
     @classmethod
     def _cell_grid(cls, t, tol):
         """
-        Uniform grid over the union of the region boxes with, per cell, the bit set of regions that can contain a point
-        of the cell: region r is dropped from a cell only when one of its rows a'x <= b + tol is violated on the whole
-        (slightly inflated) cell, i.e. min over the cell of a'x = sum_q min(a_q lo_q, a_q hi_q) > b + tol.  Critical
-        regions are mostly thin slabs: their boxes overlap everywhere, this test does not.  None when the parameter
-        space has more than 4 dimensions or a region is unbounded.
+        Uniform grid over the union of the region boxes with, per cell,
+        masks: the bit set of regions that can contain a point of the cell: region r is dropped from a cell only when one
+          of its rows a'x <= b + tol is violated on the whole (slightly inflated) cell, i.e. min over the cell of
+          a'x = sum_q min(a_q lo_q, a_q hi_q) > b + tol.  Critical regions are mostly thin slabs: their boxes overlap
+          everywhere, this test does not;
+        sure: the region of EVERY point of the cell, where the cell alone decides it: r when the whole inflated cell
+          satisfies every row of r with a margin (max over the cell of a'x <= b - margin, so for any tol >= 0 of the
+          kernel's row test) and r is the lowest bit of the cell's set (first hit, parametric_programs.py:442-463: no
+          earlier region can contain a point of the cell); -1 when the set is empty; -2 otherwise.
+        Built on the device with torch (rows x cells comparisons: 0.2 G of them for the pendulum table).  None when the
+        parameter space has more than 4 dimensions or a region is unbounded.
         """
         nreg, p, rp = t['nreg'], t['p'], t['row_ptr']
         G = cls.GRID_CELLS_PER_AXIS.get(p)
@@ -400,25 +407,50 @@ class ExplicitSolution(object):
         if not np.all(span > 0):
             return None
         h = span / G
-        axes = [np.arange(G)] * p
-        idx = np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, p)     # cell index = ((c0 G + c1) G + ...)
         pad = 1.e-9 * (1. + np.abs(lo) + np.abs(hi))          # rounding of the kernel's cell index, LP accuracy of the boxes
-        clo = lo + idx * h - pad
-        chi = lo + (idx + 1) * h + pad
+        dev = _hip.device()
+        c = np.arange(G)
+        # per axis q: lower and upper end of the (inflated) cells c_q = 0 .. G-1
+        clo = torch.as_tensor(lo[None, :] + c[:, None] * h[None, :] - pad[None, :], device=dev)       # [G x p]
+        chi = torch.as_tensor(lo[None, :] + (c[:, None] + 1) * h[None, :] + pad[None, :], device=dev)
+        cabs = torch.maximum(clo.abs(), chi.abs())
         # the kernel clamps points outside the grid into the border cells: those cells extend to the region boxes' hull,
-        # and no region accepts a point outside its own box, so the clamped look-up stays exact
-        masks = np.zeros((idx.shape[0], (nreg + 63) // 64), dtype=np.uint64)
+        # and no region accepts a point outside its own box, so the clamped look-up of the bit sets stays exact (the
+        # decided cells are only consulted for points inside the grid)
+        ncell = G ** p
+        words = (nreg + 63) // 64
+        masks = torch.zeros((ncell, words), dtype=torch.int64, device=dev)
+        first = torch.full((ncell,), -1, dtype=torch.int32, device=dev)
+        sure = torch.full((ncell,), -2, dtype=torch.int32, device=dev)
+        Ad, bd = t['dev']['A'], t['dev']['b']
+        shape = lambda q: [-1] + [G if k == q else 1 for k in range(p)]
         for r in range(nreg):
-            A = t['A'][rp[r]:rp[r + 1]]
-            b = t['b'][rp[r]:rp[r + 1]] + tol + 1.e-9
-            ok = np.ones(idx.shape[0], dtype=bool)
-            for a, bi in zip(A, b):
-                ok &= (np.minimum(a * clo, a * chi).sum(axis=1) <= bi)
-            masks[ok, r // 64] |= np.uint64(1) << np.uint64(r % 64)
-        return dict(n=G, geom=np.concatenate((lo, 1. / h)), masks=masks)
+            A = Ad[rp[r]:rp[r + 1]]                                  # [rows x p]
+            b = bd[rp[r]:rp[r + 1]]
+            amin = amax = mag = None
+            for q in range(p):
+                a = A[:, q:q + 1]                                   # [rows x 1] against [1 x G]
+                lo_q, hi_q = a * clo[None, :, q], a * chi[None, :, q]
+                tmin = torch.minimum(lo_q, hi_q).reshape(shape(q))
+                tmax = torch.maximum(lo_q, hi_q).reshape(shape(q))
+                tmag = (a.abs() * cabs[None, :, q]).reshape(shape(q))
+                amin = tmin if amin is None else amin + tmin
+                amax = tmax if amax is None else amax + tmax
+                mag = tmag if mag is None else mag + tmag
+            bb = b.reshape([-1] + [1] * p)
+            ok = (amin <= bb + (tol + 1.e-9)).all(dim=0).reshape(-1)                 # region r can touch the cell
+            full = (amax <= bb - 1.e-10 * (mag + bb.abs())).all(dim=0).reshape(-1)   # the cell lies inside region r
+            masks[:, r // 64] |= ok.to(torch.int64) << (r % 64)
+            lowest = ok & (first < 0)
+            first = torch.where(lowest, torch.full_like(first, r), first)
+            sure = torch.where(lowest & full, torch.full_like(sure, r), sure)
+        sure = torch.where(first < 0, torch.full_like(sure, -1), sure)
+        return dict(n=G, geom=np.concatenate((lo, 1. / h, hi)), masks=masks, sure=sure,
+                    decided_fraction=float((sure > -2).double().mean().item()))
 
-    def locate(self, X, nu=None, tol=1.e-7, use_boxes=True, use_grid=True):
-        """Batched look-up: X [B x p] -> device tensors (idx int32 [B], u [B x nu], V [B]); no synchronisation."""
+    def locate(self, X, nu=None, tol=1.e-7, use_boxes=True, use_grid=True, use_sure=True):
+        """Batched look-up: X [B x p] -> device tensors (idx int32 [B], u [B x nu], V [B]); no synchronisation.
+        use_boxes / use_grid / use_sure switch the pruning data off (tests: the result must not depend on them)."""
         lib = _hip.load_library()
         t = self.table(nu)
         X = _hip.to_device(X)
@@ -430,13 +462,14 @@ class ExplicitSolution(object):
         u = torch.empty((B, t['nu']), dtype=torch.float64, device=dev)
         V = torch.empty(B, dtype=torch.float64, device=dev)
         d = t['dev']
-        grid = use_grid and tol <= 1.e-7 and t['grid'] is not None
+        grid = use_grid and 0. <= tol <= 1.e-7 and t['grid'] is not None
         _hip.check(lib.pympc_point_location(t['nreg'], t['total_rows'], t['p'], t['nu'], _hip.ptr(d['A']), _hip.ptr(d['b']),
                                             _hip.ptr(d['row_ptr']), _hip.ptr(d['ux']), _hip.ptr(d['u0']), _hip.ptr(d['Vxx']),
                                             _hip.ptr(d['Vx']), _hip.ptr(d['V0']),
                                             _hip.ptr(d['box']) if (use_boxes and tol <= 1.e-7) else None,
                                             _hip.ptr(d['grid_geom']) if grid else None, t['grid']['n'] if grid else 0,
-                                            _hip.ptr(d['grid_masks']) if grid else None, _hip.ptr(X), B, float(tol),
+                                            _hip.ptr(d['grid_masks']) if grid else None,
+                                            _hip.ptr(d['grid_sure']) if (grid and use_sure) else None, _hip.ptr(X), B, float(tol),
                                             _hip.ptr(idx), _hip.ptr(u), _hip.ptr(V), _hip.stream_ptr()))
         return idx, u, V
 

@@ -144,13 +144,24 @@ def test_point_location_vs_oracle(nb, oracle):
     assert (ridx >= 0).mean() > .3 and (ridx < 0).sum() > 1000
     # the bounding-box pruning only skips work: identical outputs with and without it, ties included
     c = es.locate(X, nu=1, use_boxes=False, use_grid=False)      # plain list scan
-    for kw in (dict(use_boxes=True, use_grid=False), dict(use_boxes=False, use_grid=True), dict()):
+    for kw in (dict(use_boxes=True, use_grid=False), dict(use_boxes=False, use_grid=True), dict(use_sure=False), dict()):
         a = es.locate(X, nu=1, **kw)
         assert np.array_equal(a[0].cpu().numpy(), c[0].cpu().numpy())
         assert np.array_equal(a[1].cpu().numpy(), c[1].cpu().numpy(), equal_nan=True)
         assert np.array_equal(a[2].cpu().numpy(), c[2].cpu().numpy(), equal_nan=True)
     grid = es.table(1)['grid']
-    assert grid is not None and grid['masks'].shape == (128 * 128, 2)
+    G = es.GRID_CELLS_PER_AXIS[2]
+    assert grid is not None and tuple(grid['masks'].shape) == (G * G, 2) and tuple(grid['sure'].shape) == (G * G,)
+    # decided cells: most of the grid, and each one is right at its centre and corners (first hit of the plain scan)
+    sure = grid['sure'].cpu().numpy()
+    assert (sure > -2).mean() > .5 and (sure >= 0).any() and (sure == -1).any()
+    lo, inv, hi = grid['geom'][:2], grid['geom'][2:4], grid['geom'][4:]
+    cc = np.stack(np.meshgrid(np.arange(G), np.arange(G), indexing='ij'), axis=-1).reshape(-1, 2)
+    for off in ((.5, .5), (1e-6, 1e-6), (1 - 1e-6, 1e-6), (1e-6, 1 - 1e-6), (1 - 1e-6, 1 - 1e-6)):
+        Xc = lo + (cc + np.array(off)) / inv
+        plain = es.locate(Xc, nu=1, use_boxes=False, use_grid=False)[0].cpu().numpy()
+        dec = sure > -2
+        assert np.array_equal(plain[dec], sure[dec])
     # points outside the grid (clamped into the border cells) and far outside it
     far = np.vstack((X[:2000] * 3.0, X[:2000] * 1e6, X[:100] * 0.0))
     a = es.locate(far, nu=1); c = es.locate(far, nu=1, use_boxes=False, use_grid=False)
@@ -243,6 +254,11 @@ def test_full_size_grid_vs_oracle(nb, oracle):
     g = torch.linspace(-.5, .5, n, dtype=torch.float64, device='cuda')
     Xd = torch.stack(torch.meshgrid(g, g, indexing='ij'), dim=-1).reshape(-1, 2).contiguous()
     idx, u, V = es.locate(Xd, nu=1)
+    # (the decided cells change which lanes scan, never the result: bitwise the same without them)
+    idx0, u0, V0 = es.locate(Xd, nu=1, use_sure=False)
+    assert torch.equal(idx, idx0) and torch.equal(torch.nan_to_num(u, nan=-7.), torch.nan_to_num(u0, nan=-7.))
+    assert torch.equal(torch.nan_to_num(V, nan=-7.), torch.nan_to_num(V0, nan=-7.))
+    del idx0, u0, V0
     idx = idx.cpu().numpy(); u = u.cpu().numpy(); V = V.cpu().numpy()
     X = Xd.cpu().numpy()
     table = _table(es, 1)
@@ -328,7 +344,7 @@ def test_nan_points_and_empty_table(nb, oracle):
     oV = torch.zeros(1000, dtype=torch.float64, device='cuda')
     rp = torch.zeros(1, dtype=torch.int32, device='cuda')
     _hip.check(lib.pympc_point_location(0, 0, 2, 1, None, None, _hip.ptr(rp), None, None, None, None, None, None, None, 0, None,
-                                        _hip.ptr(Xd), 1000, 1e-7, _hip.ptr(oi), _hip.ptr(ou), _hip.ptr(oV), _hip.stream_ptr()))
+                                        None, _hip.ptr(Xd), 1000, 1e-7, _hip.ptr(oi), _hip.ptr(ou), _hip.ptr(oV), _hip.stream_ptr()))
     torch.cuda.synchronize()
     assert bool((oi == -1).all()) and bool(torch.isnan(oV).all()) and bool(torch.isnan(ou).all())
 

@@ -58,6 +58,10 @@ const char *pympc_hip_last_error(void);
  *                        that needs a column return PYMPC_MAXITER: how the tests reach that status)
  *   "reserved_cus"       compute units the persistent launches leave free (default 0), for callers whose transfers run
  *                        as copy kernels beside the solve
+ *   "dynamic_chunks"     1 (default): with a certificate table and >= 524 288 states, the workgroups of the Gram-form and
+ *                        Lawson-Hanson kernels draw chunks of 256 states from a device counter per kernel (in the table's
+ *                        header) and share them out to their waves through LDS; 0: a fixed share of interleaved slices
+ *                        per workgroup.  Which wave solves a state never changes its result
  * Process-wide, read at launch time; not meant to be changed while other threads launch.
  */
 int pympc_hip_tune(const char *key, long long value, long long *previous);
@@ -110,7 +114,8 @@ int pympc_mpqp_solve_batch(int n, int m, int p, const double *ws, const double *
  * of device memory owned by the caller, zeroed by pympc_mpqp_cuts_reset before first use and whenever `ws` is
  * prepared again; it belongs to ONE prepared mpQP, is read and appended to by the kernel and can be kept across calls.
  * Launches that share a table must be ordered on ONE stream (the screening kernel reads the entries that were complete
- * when it started through the scalar cache; a concurrent launch appending to the same table is not supported).
+ * when it started through the scalar cache, and the table's header holds the chunk counters of the launch's kernels; a
+ * concurrent launch on the same table is not supported).
  * NULL, p = 0 or p > 8: no certificates (plain solve).
  */
 size_t pympc_mpqp_cuts_doubles(int p);
@@ -137,7 +142,7 @@ int pympc_mpqp_solve_batch_cuts(int n, int m, int p, const double *ws, double *c
 /*
  * pympc_mpqp_solve_batch_cuts for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The certificate table
- * lives in a file-scope device array of the library (18 448 bytes per GPU, held until the process ends; its device
+ * lives in a file-scope device array of the library (18 816 bytes per GPU, held until the process ends; its device
  * address is looked up once per GPU with hipGetSymbolAddress on the first call there) instead of caller memory, and
  * is emptied at the start of EVERY call (hipMemsetAsync on `stream`), because the certificates of the last call belong
  * to that call's mpQP.  Needs 1 <= p <= 8 (the certificates' limit): anything else returns PYMPC_ERR_UNSUPPORTED.

@@ -65,6 +65,7 @@ struct Tune {
     std::atomic<long long> learn_min_batch{131072};              // certificate-learning pre-pass from this many states
     std::atomic<long long> nnls_itmax_factor{3};                 // NNLS iteration limit = factor * columns (scipy: 3)
     std::atomic<long long> reserved_cus{0};                      // compute units the persistent launches leave free
+    std::atomic<long long> dynamic_chunks{1};                    // 1: chunks of states from a device counter (Gram / solve kernels), 0: static shares
 };
 Tune g_tune;
 
@@ -188,6 +189,11 @@ int check_prep(const PrepGeom &G, int n, int m, int p)
 #define PYMPC_LEARN_STATES 8192
 #endif
 constexpr long long kLearnStates = PYMPC_LEARN_STATES;
+constexpr size_t kSolveCtlBytes = kSchedCtlInts * sizeof(int);   // qp_solve_kernel's control block in LDS (ticket, flags, chunk list)
+// states per chunk a workgroup requests from the launch's device counter (SolveParams::sched)
+#ifndef PYMPC_DYN_CHUNK
+#define PYMPC_DYN_CHUNK 256
+#endif
 
 // Common launch geometry of the solve kernel.
 int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t st, bool learn_pass = false)
@@ -211,13 +217,13 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     }
     // a matrix too large to be staged beside four problems stays in global memory (one workspace, ws_stride 0, read
     // through L2 by every wave) instead of being refused
-    if (shared && shared_lds(n, P.L).total * 8 + 16 + 4 * wave_bytes > kLdsBytes) shared = false;
+    if (shared && shared_lds(n, P.L).total * 8 + kSolveCtlBytes + 4 * wave_bytes > kLdsBytes) shared = false;
     if (!shared || p < 1 || p > kCutPMax) P.cuts = nullptr;   // certificates belong to ONE mpQP with a parameter
     const size_t shared_bytes = shared ? shared_lds(n, P.L).total * 8 : 0;
-    if (shared_bytes + 16 + wave_bytes > kLdsBytes)
+    if (shared_bytes + kSolveCtlBytes + wave_bytes > kLdsBytes)
         return fail(PYMPC_ERR_UNSUPPORTED, "QP %dx%d (p=%d) does not fit the 160 KiB LDS (%zu + %zu B)", n, m, p,
                     shared_bytes, wave_bytes);
-    int nwaves = (int)((kLdsBytes - shared_bytes - 16) / wave_bytes);
+    int nwaves = (int)((kLdsBytes - shared_bytes - kSolveCtlBytes) / wave_bytes);
     // without a staged matrix keep workgroups small so several fit a CU and balance at wave granularity
     const int max_waves = mt <= 8 ? 12 : 4;   // = solve_max_waves<MT>() (launch bounds of the kernel)
     const int cap = shared ? max_waves : 4;
@@ -225,7 +231,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
     if (shared && nwaves > 4) nwaves &= ~3;   // a multiple of the 4 SIMDs
     if ((long long)nwaves > P.B) nwaves = (int)P.B;
     if (nwaves < 1) nwaves = 1;
-    const size_t lds_bytes = shared_bytes + 16 + wave_bytes * nwaves;
+    const size_t lds_bytes = shared_bytes + kSolveCtlBytes + wave_bytes * nwaves;
     long long chunk = nwaves, nwg;
     if (shared) {
         // one persistent workgroup per CU over interleaved slices (qp_solve_kernel); slices of 8 problems once the batch
@@ -240,6 +246,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
         if (nwg < 1) nwg = 1;
         P.persist = 1;
         P.chunk = (int)chunk;
+        P.sched = nullptr;
         // screening pass: states with a feasible unconstrained minimiser (and those a stored certificate rejects) finish here
         P.screened = 0;
         if (!learn_pass && p >= 1 && p <= 8 && P.x_stride >= p && P.B <= 0x7fffffffLL) {
@@ -263,6 +270,9 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
             }
 #undef PYMPC_SCREEN_CASE
             if (int rc = check_launch("mpqp_screen_kernel")) return rc;
+            // with a certificate table (whose header holds the counters, cleared by the screening kernel) and a batch
+            // that gives every workgroup several chunks, the two kernels below draw their states from a device counter
+            const bool dynamic = P.cuts != nullptr && g_tune.dynamic_chunks.load() != 0 && P.B >= 8LL * PYMPC_DYN_CHUNK * ncu;
             // Gram-form pass (qp_gram.hpp): what the lane path left pending and ends with up to kGramK active constraints
             // is finished here, without the matrix in LDS; the rest stays pending for the solve kernel below
             // (batches too small to keep the chip busy pay for its launch and staging more than it saves the solve kernel)
@@ -271,6 +281,10 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
                 int gslice = kGramSlice;   // states per ticket; smaller while the batch does not give every wave a slice
                 while (gslice > 1 && P.B < (long long)gslice * (kGramThreads / 64) * ncu) gslice >>= 1;
                 G.chunk = gslice;
+                if (dynamic) {
+                    G.sched = reinterpret_cast<int *>(P.cuts) + kCutTicketGram;
+                    G.dyn_chunk = PYMPC_DYN_CHUNK;
+                }
                 const size_t gbytes = gram_lds_doubles(p, P.L) * sizeof(double);   // <= 10 * 512 * 8 + tables: below 64 KiB
                 const long long gslices = (P.B + gslice - 1) / gslice;
                 const long long gwant = (gslices + kGramThreads / 64 - 1) / (kGramThreads / 64);
@@ -282,6 +296,10 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
                 case 8: hipLaunchKernelGGL(mpqp_gram_kernel<8>, dim3((unsigned)gg), dim3(kGramThreads), gbytes, st, G); break;
                 }
                 if (int rc = check_launch("mpqp_gram_kernel")) return rc;
+            }
+            if (dynamic) {
+                P.sched = reinterpret_cast<int *>(P.cuts) + kCutTicketSolve;
+                P.dyn_chunk = PYMPC_DYN_CHUNK;
             }
         }
     } else {
@@ -297,7 +315,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
 // infeasibility certificates, sized for the largest parameter count the certificates support.  Every GPU the library
 // runs on holds its own copy until the process ends.  In host code the array's NAME is only a handle for
 // hipGetSymbolAddress: the device address is looked up once per device and kept in g_scratch[dev].
-constexpr size_t kScratchDoubles = kCutHeader + (size_t)(kCutPMax + 1) * kCutMax;   // 2 306 doubles = 18 448 B
+constexpr size_t kScratchDoubles = kCutHeader + (size_t)(kCutPMax + 1) * kCutMax;   // 2 352 doubles = 18 816 B
 static __device__ __align__(256) double scratch[kScratchDoubles];
 double *g_scratch[kMaxDevices] = {};
 std::mutex g_scratch_mu;
@@ -348,6 +366,7 @@ int pympc_hip_tune(const char *key, long long value, long long *previous)
         {"learn_min_batch", &g_tune.learn_min_batch, 1, 1LL << 40},
         {"nnls_itmax_factor", &g_tune.nnls_itmax_factor, 0, 1000},
         {"reserved_cus", &g_tune.reserved_cus, 0, 128},
+        {"dynamic_chunks", &g_tune.dynamic_chunks, 0, 1},
     };
     for (auto &k : knobs)
         if (strcmp(key, k.name) == 0) {

@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(kGramThreads) __attribute__((amdgpu_waves_per_
 {
     constexpr int mp = 64 * MT;
     extern __shared__ double glds[];   // cn | m0 | Gm (p rows) | tables: gram_lds_doubles(p, L)
-    __shared__ int ticket;
+    __shared__ int ctl[kSchedCtlInts];   // slice ticket and chunk list (sched_next)
     if (P.ws_status && P.ws_status[0] != 0) return;   // (a workspace that is not positive definite: the solve kernel reports it)
     const WsLayout &L = P.L;
     const int p = P.p;
@@ -364,17 +364,29 @@ __global__ void __launch_bounds__(kGramThreads) __attribute__((amdgpu_waves_per_
     for (int e = threadIdx.x; e < mp; e += blockDim.x) { cnl[e] = P.ws[L.cn + e]; m0l[e] = P.ws[L.m0 + e]; }
     for (int e = threadIdx.x; e < p * mp; e += blockDim.x) Gml[e] = P.ws[L.Gm + e];
     for (int e = threadIdx.x; e < (int)(L.total - L.u0); e += blockDim.x) tabl[e] = P.ws[L.u0 + e];
-    if (threadIdx.x == 0) ticket = 0;
+    sched_init(P, ctl);
     __syncthreads();
+    if (P.sched) {
+        sched_first(P, ctl);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, S = P.chunk;
     const long long nslice = (P.B + S - 1) / S;
     const long long mine = blockIdx.x < nslice ? (nslice - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    ChunkSched W;
+    W.solo = -1; W.solo_s = 0;
     for (;;) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(&ticket, 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= mine) break;
-        const long long base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
+        long long base;
+        if (P.sched) {
+            base = sched_next(P, ctl, W, lane, S);
+            if (base < 0) break;
+        } else {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(ctl, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= mine) break;
+            base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
+        }
         const bool pend = lane < S && base + lane < P.B && P.status[base + lane] == kStatusPending;
         unsigned long long todo = __ballot(pend);
         while (todo != 0ull) {

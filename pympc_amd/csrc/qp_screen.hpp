@@ -297,6 +297,9 @@ __global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams
     const int tid = threadIdx.x;
     const bool ws_ok = P.ws_status ? (P.ws_status[0] == 0) : true;
     if (tid < 2) q_cnt[tid] = 0;
+    if (P.cuts && blockIdx.x == 0 && tid < 2)   // chunk counters of the kernels that follow in this launch (SolveParams::sched)
+        __hip_atomic_store(reinterpret_cast<int *>(P.cuts) + (tid == 0 ? kCutTicketGram : kCutTicketSolve), 0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
 
     // run stage 1 / stage 2 on the top `take` entries of their queues

@@ -62,6 +62,9 @@ struct SolveParams {
     long long rhs_stride;
     int raw;
     int learn;                  // SHARED: this launch is the certificate-learning pre-pass (returns at once if the table is not empty)
+    int *sched;                 // SHARED: device counter (zero at launch; the screening kernel clears it) that hands out chunks of
+    int dyn_chunk;              //   dyn_chunk states (a multiple of `chunk`) to the WORKGROUPS of the launch, whose waves share a
+                                //   chunk out in slices of `chunk` through LDS.  null: static interleaved slices per workgroup
     double *cuts;               // learned infeasibility certificates of this mpQP (cut_table_doubles(p) doubles) or null
     const double *gram;         // SHARED: Gram matrix of the constant rows [mp x mp] (ws_layout.hpp) or null
     int itmax_factor;           // NNLS iteration limit = itmax_factor * columns (scipy.optimize.nnls: 3)
@@ -97,11 +100,15 @@ __device__ __forceinline__ int slot_of(int j) { return 2 * (j >> 7) + (j & 1); }
 // with a relative margin of 1e-6; anything closer to the boundary takes the full solve, so the decision is the
 // reference's (its own threshold is a residual of 1e-7).  A certificate is stored only after its x-independent part
 // has been verified to rounding level (|M'y| <= 1e-11 sum |M||y| row by row).
-// Table: int32 count, int32 lock | c[kCutMax] | d_0[kCutMax] | ... | d_{p-1}[kCutMax].  One writer at a time (try-lock,
-// never waited for); an entry is complete in L2 before `count` covers it, readers bypass the non-coherent vector L1.
+// Table: header | c[kCutMax] | d_0[kCutMax] | ... | d_{p-1}[kCutMax].  One writer at a time (try-lock, never waited
+// for); an entry is complete in L2 before `count` covers it, readers bypass the non-coherent vector L1.  The header
+// also holds the chunk counters of a launch's Gram-form and Lawson-Hanson kernels (SolveParams::sched), each on a
+// cache line of its own, away from `count`, which every running solve polls: the table is the one piece of device
+// memory that belongs to one launch at a time.
 constexpr int kCutMax = 256;
 constexpr int kCutPMax = 8;
-constexpr int kCutHeader = 2;
+constexpr int kCutHeader = 48;   // three 128-byte lines: count, lock, base, spare | chunk counter (Gram kernel) | chunk counter (solve kernel)
+constexpr int kCutTicketGram = 32, kCutTicketSolve = 64;   // int32 slots of the header
 constexpr double kCutMargin = 1e-6;
 constexpr double kCutVerify = 1e-11;
 constexpr int kCutLearnSkip = 16;    // entries from which the learning pre-pass of a launch is skipped
@@ -606,6 +613,73 @@ __host__ __device__ inline SharedLds shared_lds(int n, const WsLayout &L)
     return S;
 }
 
+// Chunks of states for a persistent workgroup from ONE device counter, shared out to its waves in slices through LDS.
+// Why two levels: the chip's eight L2s are not coherent with each other, so a device-scope atomic is served memory-side,
+// ~14 ns apiece on one address -- one request per slice and wave (47 000 a step) cost more than the balancing gained; one
+// request per chunk and workgroup is a few thousand.  LDS: ctl[0] = slice ticket, ctl[1 .. kSchedList] = the device
+// chunk index of the workgroup's k-th chunk (-1 until it is known).  The wave that draws the first slice of chunk k
+// requests chunk k + 1 (so the answer is there a whole chunk ahead) and publishes it; a wave that needs a chunk which is
+// not published yet polls LDS -- its publisher never waits for anything but the atomic's return, so nobody waits for
+// ever.  A workgroup that outruns its list (kSchedList chunks) lets each wave take whole chunks for itself.
+constexpr int kSchedList = 60;
+constexpr int kSchedCtlInts = 4 + kSchedList;     // [0] slice ticket, [1] learn flag (qp_solve_kernel), [2], [3] spare, list
+
+struct ChunkSched {
+    int solo, solo_s;   // a wave on its own: chunk at hand (-1: list mode) and next slice of it
+};
+
+__device__ __forceinline__ void sched_init(const SolveParams &P, int *ctl)
+{
+    // (called by every thread before the workgroup's first barrier)
+    for (int e = threadIdx.x; e < kSchedList; e += blockDim.x) ctl[4 + e] = -1;
+    if (threadIdx.x == 0) ctl[0] = 0;
+}
+__device__ __forceinline__ void sched_first(const SolveParams &P, int *ctl)
+{
+    // (thread 0, after the barrier that follows sched_init and before the next one)
+    if (threadIdx.x == 0) __hip_atomic_store(ctl + 4, atomicAdd(P.sched, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// next slice of this wave: first state of it, or -1 when the launch has no more (wave-uniform)
+__device__ __forceinline__ long long sched_next(const SolveParams &P, int *ctl, ChunkSched &W, int lane, int S)
+{
+    const int C = P.dyn_chunk / S;
+    const long long nchunks = (P.B + P.dyn_chunk - 1) / P.dyn_chunk;
+    int g, s;
+    if (W.solo < 0) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(ctl, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int k = t / C;
+        s = t - k * C;
+        if (k < kSchedList) {
+            if (s == 0 && k + 1 < kSchedList && lane == 0)
+                __hip_atomic_store(ctl + 4 + k + 1, atomicAdd(P.sched, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                g = __hip_atomic_load(ctl + 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (g >= 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            g = __builtin_amdgcn_readfirstlane(g);
+        } else {
+            W.solo = 0;
+            W.solo_s = C;   // (asks for a chunk below)
+            g = 0; s = 0;
+        }
+    }
+    if (W.solo >= 0) {
+        if (W.solo_s >= C) {
+            int c = 0;
+            if (lane == 0) c = atomicAdd(P.sched, 1);
+            W.solo = __builtin_amdgcn_readfirstlane(c);
+            W.solo_s = 0;
+        }
+        g = W.solo;
+        s = W.solo_s++;
+    }
+    if (g >= nchunks) return -1;
+    return (long long)g * P.dyn_chunk + (long long)s * S;
+}
+
 // Workgroup = NW waves; it owns problems [blockIdx.x * chunk, ...) and hands them to its waves through an LDS
 // ticket.  SHARED: the constant rows Mt / m0 / Gm and the objective tables are staged in LDS once per workgroup.
 // waves per workgroup: 12 (3 per SIMD, 168 VGPRs) up to 8 columns per lane, 4 (512 VGPRs) beyond, so that
@@ -630,7 +704,7 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
         __syncthreads();
         if (ticket[1] != 0) return;
     }
-    double *waves = lds + sharedD + 2;
+    double *waves = lds + sharedD + kSchedCtlInts / 2;
     const int wave = threadIdx.x >> 6;
     if (SHARED) {
         const double *src = P.ws;
@@ -639,8 +713,12 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
         for (int e = threadIdx.x; e < mp; e += blockDim.x) lds[S_.cn + e] = src[P.L.cn + e];
     }
     for (int e = threadIdx.x; e < (int)(blockDim.x >> 6) * P.wave_doubles; e += blockDim.x) waves[e] = 0.0;   // (I2), (I3)
-    if (threadIdx.x == 0) *ticket = 0;
+    sched_init(P, ticket);
     __syncthreads();
+    if (SHARED && P.sched) {
+        sched_first(P, ticket);
+        __syncthreads();
+    }
     double *wl = waves + (size_t)wave * P.wave_doubles;
     if (SHARED) {
         // One persistent workgroup per CU (the constant rows are staged once per CU): workgroup g owns the slices
@@ -651,12 +729,20 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
         const int lane = threadIdx.x & 63, S = P.chunk;
         const long long nslice = (P.B + S - 1) / S;
         const long long mine = blockIdx.x < nslice ? (nslice - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        ChunkSched W;
+        W.solo = -1; W.solo_s = 0;
         for (;;) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(ticket, 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= mine) break;
-            const long long base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
+            long long base;
+            if (P.sched) {   // a static share per workgroup ends 15 - 25 % after its mean (~170 solves of 3 .. 24 pivots each)
+                base = sched_next(P, ticket, W, lane, S);
+                if (base < 0) break;
+            } else {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(ticket, 1);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= mine) break;
+                base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
+            }
             bool pend = lane < S && base + lane < P.B;
             if (P.screened && pend) pend = (P.status[base + lane] == kStatusPending);
             unsigned long long todo = __ballot(pend);

@@ -218,7 +218,8 @@ class PreparedMpqp(object):
         if n <= 1:
             return
         KC = 256                                                    # kCutMax (csrc/qp_wave.hpp)
-        body = self.cuts[2:2 + (self.p + 1) * KC].view(self.p + 1, KC)
+        H = self.cuts.numel() - (self.p + 1) * KC                   # header doubles (kCutHeader)
+        body = self.cuts[H:H + (self.p + 1) * KC].view(self.p + 1, KC)
         tab = body[:, :n].cpu().numpy()
         cc, D = tab[0], tab[1:]                                     # c [n], d [p x n]
         k = self.SEED_STRIDE

@@ -110,4 +110,4 @@ def test_cuts_disabled_without_parameters():
     lib = _hip.load_library()
     assert lib.pympc_mpqp_cuts_doubles(0) == 0
     assert lib.pympc_mpqp_cuts_doubles(9) == 0
-    assert lib.pympc_mpqp_cuts_doubles(4) == 2 + 5 * 256
+    assert lib.pympc_mpqp_cuts_doubles(4) == 48 + 5 * 256

@@ -181,7 +181,7 @@ def c4():
     # which points / wavefronts the decided cells settle (a wavefront = 64 consecutive points of the list)
     G, geom = tab['grid']['n'], torch.as_tensor(tab['grid']['geom'], device='cuda')
     cell = ((X - geom[:2]) * geom[2:4]).floor().clamp_(0, G - 1).long()
-    dec = tab['grid']['sure'][cell[:, 0] * G + cell[:, 1]] > -2
+    dec = tab['grid']['sure'][cell[:, 0] * G + cell[:, 1]] != -2
     dec |= ((X < geom[:2]) | (X > geom[4:])).any(dim=1)
     wave_dec = torch.nn.functional.pad(dec, (0, (-B) % 64), value=True).reshape(-1, 64).all(dim=1)
     sample = X[::50].cpu().numpy()
@@ -192,7 +192,8 @@ def c4():
     return dict(config="C4", workload="explicit MPC look-up, inverted pendulum N=6 (71 critical regions, %d rows), 3163^2 = %d grid points: (region, u0, V)" % (int(rp[-1]), B),
                 value=B / t, unit="points/s", ms=t * 1e3, covered_fraction=float((idx >= 0).double().mean()),
                 ms_table_construction_facet_flipping=t_build * 1e3, ms_device_table_boxes_and_cell_grid=t_table * 1e3,
-                ms_without_decided_cells=t_scan * 1e3, cells_per_axis=G, cells_decided=tab['grid']['decided_fraction'],
+                ms_without_decided_cells=t_scan * 1e3, cells_per_axis=G, cells_decided=tab['grid']['decided_fraction'], cells_with_decision_list=tab['grid']['listed_fraction'],
+                scan_pass_needed=tab['grid']['needs_scan'],
                 points_decided_by_their_cell=float(dec.double().mean()), wavefronts_without_scan=float(wave_dec.double().mean()),
                 roofline=dict(bound="hbm", achieved=by / t / 1e9, peak=PEAK_HBM, unit="GB/s", frac=by / t / 1e9 / PEAK_HBM,
                               algorithmic_bytes_per_launch=by, note="36 B per point; the table is read through the scalar cache and L2"),

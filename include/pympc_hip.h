@@ -275,13 +275,19 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
  * region r for any tol >= 0 and no earlier region can contain a point of the cell; -1 = no region can; -2 = undecided
  * (the cell's bit set is scanned).  Points outside [lower corner, upper corner] are taken to lie in no region, so the
  * grid must cover every region.  Unlike the boxes and bit sets this one DECIDES: a wrong entry is a wrong result.
+ * grid_lists (int32 pool, may be NULL): grid_sure <= -3 means -3 - grid_sure is the offset of the cell's decision list
+ * [ncand, (region, nrows, row_0 .. row_{nrows-1}) x ncand]: the candidate regions of the cell in ascending order, each
+ * with the rows (indices into A / b) that do not hold on the whole cell; a point of the cell lies in the first
+ * candidate whose listed rows it satisfies (A x - b <= tol, as everywhere), in no region if there is none.  Without the
+ * pool such cells count as undecided.  grid_scan: 0 = the caller guarantees that no cell is -2 (the scan pass over the
+ * marked points is not launched); anything else = launch it.
  * Outputs: idx [B] int32 (-1 when uncovered), u [B x nu] (NaN when uncovered), V [B] (NaN when uncovered).
  * ------------------------------------------------------------------------------------------------- */
 int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
                          const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
                          const double *Vx, const double *V0, const double *box, const double *grid_geom, int grid_n,
-                         const uint64_t *grid_masks, const int32_t *grid_sure, const double *X, int64_t B, double tol,
-                         int32_t *idx, double *u, double *V, void *stream);
+                         const uint64_t *grid_masks, const int32_t *grid_sure, const int32_t *grid_lists, int grid_scan,
+                         const double *X, int64_t B, double tol, int32_t *idx, double *u, double *V, void *stream);
 
 #ifdef __cplusplus
 }

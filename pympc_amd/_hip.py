@@ -49,8 +49,8 @@ SIGNATURES = {
     "pympc_lp_limits": (None, [ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "pympc_lp_solve_batch": (_i, [_i, _i, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp]),
-    "pympc_point_location": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64,
-                                  _d, _vp, _vp, _vp, _vp]),
+    "pympc_point_location": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i,
+                                  _vp, _i64, _d, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -24,7 +24,10 @@
 // inside region r and no earlier region can touch the cell, -1 when no region can touch it, -2 otherwise.  A point whose
 // cell is decided needs no scan at all (one 4-byte gather from a table that stays in L2): point_cells_kernel settles
 // those and marks the rest, and only the wavefronts with a marked point -- those that touch a region boundary -- scan,
-// with the hull of their marked points.
+// with the hull of their marked points.  A cell that a boundary crosses can still be decided without the scan: over one
+// small cell nearly every row of a candidate region holds everywhere, so the host lists, per such cell and in region
+// order, the candidates with only the rows that CROSS the cell (grid_sure = -3 - offset into grid_lists: [ncand,
+// (region, nrows, row ...) ...]); the point's lane walks its cell's list -- a handful of row evaluations.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,6 +46,7 @@ struct PlParams {
     const double *grid_geom;              // [3 p]: lower corner of the cell grid, 1 / cell size per axis, upper corner; or null
     const unsigned long long *grid_masks; // [grid_n^p x ceil(nreg / 64)]: bit r of a cell = region r can touch the cell
     const int32_t *grid_sure;             // [grid_n^p]: decided cells (see above) or null
+    const int32_t *grid_lists;            // decision lists of the cells with grid_sure <= -3 (pool of int32) or null
     int grid_n;                           // cells per axis
     const double *X;
     long long B;
@@ -350,6 +354,35 @@ __global__ void __launch_bounds__(256) point_cells_kernel(PlParams P)
             }
             sure[u] = P.grid_sure[cell];
             if (!in) sure[u] = -1;
+        }
+        if (P.grid_lists) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (sure[u] <= -3) {
+                    // decision list of the cell: first candidate region, in list order, whose crossing rows all hold (rows
+                    // evaluated as pl_scan evaluates them); the last entry may have no rows (it holds the whole cell)
+                    const int32_t *lp = P.grid_lists + (-3 - sure[u]);
+                    const int nc = lp[0];
+                    int pos = 1, f = -1;
+                    for (int c = 0; c < nc && f < 0; ++c) {
+                        const int r = lp[pos], nr = lp[pos + 1];
+                        bool in = true;
+                        for (int j = 0; j < nr; ++j) {
+                            const int row = lp[pos + 2 + j];
+                            double s = -P.b[row];
+#pragma unroll
+                            for (int q = 0; q < PD; ++q) s = fma(P.A[(size_t)row * PD + q], x[u][q], s);
+                            in = in && (s <= P.tol);
+                        }
+                        pos += 2 + nr;
+                        if (in) f = r;
+                    }
+                    sure[u] = f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) sure[u] = max(sure[u], -2);   // (no lists given: such a cell is left to the scan)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

@@ -352,7 +352,7 @@ __global__ void cuts_mark_kernel(double *cuts, int restore)
 
 extern "C" {
 
-int pympc_hip_abi_version(void) { return 8; }   // 8: pympc_point_location takes grid_sure (decided cells), grid_geom is [3 p]
+int pympc_hip_abi_version(void) { return 8; }   // 8: pympc_point_location takes grid_sure / grid_lists / grid_scan (decided cells), grid_geom is [3 p]
 
 const char *pympc_hip_last_error(void) { return g_err; }
 
@@ -831,8 +831,8 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
 int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *A, const double *b,
                          const int32_t *row_ptr, const double *ux, const double *u0, const double *Vxx,
                          const double *Vx, const double *V0, const double *box, const double *grid_geom, int grid_n,
-                         const uint64_t *grid_masks, const int32_t *grid_sure, const double *X, int64_t B, double tol,
-                         int32_t *idx, double *u, double *V, void *stream)
+                         const uint64_t *grid_masks, const int32_t *grid_sure, const int32_t *grid_lists, int grid_scan,
+                         const double *X, int64_t B, double tol, int32_t *idx, double *u, double *V, void *stream)
 {
     if (nreg < 0 || total_rows < 0 || p < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_point_location: bad shape");
     if (p > 8) return fail(PYMPC_ERR_UNSUPPORTED, "point location supports up to 8 parameters, got %d", p);
@@ -852,6 +852,7 @@ int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *
         P.grid_geom = grid_geom; P.grid_n = grid_n;
         P.grid_masks = reinterpret_cast<const unsigned long long *>(grid_masks);
         P.grid_sure = grid_sure;
+        P.grid_lists = grid_sure ? grid_lists : nullptr;
     }
     const size_t lds = 0;
     const int threads = 256;
@@ -869,7 +870,8 @@ int pympc_point_location(int nreg, int total_rows, int p, int nu, const double *
         if (marked) {                                                                             \
             const long long per = (long long)threads * pl_batches<PD>();                          \
             hipLaunchKernelGGL(point_cells_kernel<PD>, dim3(balanced((B + per - 1) / per)), dim3(threads), 0, st, P); \
-            hipLaunchKernelGGL((point_location_kernel<PD, true>), dim3(nwg), dim3(threads), lds, st, P);  \
+            if (grid_scan || !P.grid_lists)                                                       \
+                hipLaunchKernelGGL((point_location_kernel<PD, true>), dim3(nwg), dim3(threads), lds, st, P); \
         } else {                                                                                  \
             hipLaunchKernelGGL((point_location_kernel<PD, false>), dim3(nwg), dim3(threads), lds, st, P); \
         }                                                                                         \

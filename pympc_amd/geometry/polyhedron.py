@@ -345,7 +345,7 @@ class Polyhedron(object):
             idx = torch.empty(B, dtype=torch.int32, device=X.device)
             V = torch.empty(B, dtype=torch.float64, device=X.device)
             _hip.check(lib.pympc_point_location(1, m, p, 0, _hip.ptr(Ad), _hip.ptr(bd), _hip.ptr(row_ptr), None, None,
-                                                _hip.ptr(z), _hip.ptr(z), _hip.ptr(z), None, None, 0, None, None, _hip.ptr(X), B,
+                                                _hip.ptr(z), _hip.ptr(z), _hip.ptr(z), None, None, 0, None, None, None, 1, _hip.ptr(X), B,
                                                 float(t), _hip.ptr(idx), None, _hip.ptr(V), _hip.stream_ptr()))
             return idx == 0
 

@@ -332,6 +332,7 @@ class ExplicitSolution(object):
             t['dev']['grid_geom'] = _hip.to_device(t['grid']['geom'])
             t['dev']['grid_masks'] = t['grid']['masks']
             t['dev']['grid_sure'] = t['grid']['sure']
+            t['dev']['grid_lists'] = t['grid']['lists']
         self._table = t
         return t
 
@@ -379,7 +380,7 @@ class ExplicitSolution(object):
         box[:, p:] = hi + pad * (1. + np.abs(hi))
         return box
 
-    GRID_CELLS_PER_AXIS = {1: 4096, 2: 256, 3: 32, 4: 12}
+    GRID_CELLS_PER_AXIS = {1: 4096, 2: 512, 3: 32, 4: 12}
 
     @classmethod
     def _cell_grid(cls, t, tol):
@@ -445,8 +446,84 @@ class ExplicitSolution(object):
             first = torch.where(lowest, torch.full_like(first, r), first)
             sure = torch.where(lowest & full, torch.full_like(sure, r), sure)
         sure = torch.where(first < 0, torch.full_like(sure, -1), sure)
-        return dict(n=G, geom=np.concatenate((lo, 1. / h, hi)), masks=masks, sure=sure,
-                    decided_fraction=float((sure > -2).double().mean().item()))
+        decided = float((sure > -2).double().mean().item())
+        lists, sure, listed = cls._cell_lists(t, G, clo, chi, cabs, sure, tol)
+        return dict(n=G, geom=np.concatenate((lo, 1. / h, hi)), masks=masks, sure=sure, lists=lists,
+                    decided_fraction=decided, listed_fraction=listed,
+                    needs_scan=bool((sure == -2).any().item()))
+
+    LIST_MAX_INTS = 48        # longest decision list of a cell (beyond it the cell is left to the scan)
+
+    @classmethod
+    def _cell_lists(cls, t, G, clo, chi, cabs, sure, tol):
+        """
+        Decision lists for the cells no single region decides (those a region boundary crosses).  Over one small cell
+        nearly every row of a candidate region holds on the whole cell (max over the cell of a'x <= b - margin): only the
+        few rows that CROSS the cell can tell its points apart.  Per undecided cell, in region order (first hit,
+        parametric_programs.py:442-463), the candidate regions (those no row excludes from the cell, as in the bit sets)
+        with their crossing rows; the list ends at the first candidate without a crossing row (it holds the whole cell).
+        A point of the cell lies in a candidate iff it satisfies the crossing rows -- evaluated by the kernel exactly as
+        the scan evaluates them -- so the first candidate that passes is the scan's region, and none passing means no
+        region.  int32 pool: [ncand, (region, nrows, row ...) ...]; sure[cell] = -3 - offset of the cell's list.
+        Returns (pool tensor, sure, fraction of cells with a list).
+        """
+        nreg, p, rp = t['nreg'], t['p'], t['row_ptr']
+        dev = sure.device
+        und = torch.nonzero(sure == -2).reshape(-1)
+        pool = [0]
+        if und.numel() == 0:
+            return torch.zeros(1, dtype=torch.int32, device=dev), sure, 0.
+        # cell coordinates per axis (cell index = ((c_0 G + c_1) G + ...))
+        coords = []
+        rem = und.clone()
+        for q in range(p - 1, -1, -1):
+            coords.insert(0, rem % G)
+            rem = rem // G
+        Ad, bd = t['dev']['A'], t['dev']['b']
+        cand_u, cand_r, cand_k, row_u, row_r, row_i = [], [], [], [], [], []
+        for r in range(nreg):
+            A = Ad[rp[r]:rp[r + 1]]
+            b = bd[rp[r]:rp[r + 1]][:, None]
+            amin = amax = mag = 0.
+            for q in range(p):
+                a = A[:, q:q + 1]
+                lo_q, hi_q = a * clo[coords[q], q][None, :], a * chi[coords[q], q][None, :]
+                amin = amin + torch.minimum(lo_q, hi_q)
+                amax = amax + torch.maximum(lo_q, hi_q)
+                mag = mag + a.abs() * cabs[coords[q], q][None, :]
+            touch = (amin <= b + (tol + 1.e-9)).all(dim=0)
+            cross = touch[None, :] & ~(amax <= b - 1.e-10 * (mag + b.abs()))
+            tu = torch.nonzero(touch).reshape(-1)
+            if tu.numel() == 0:
+                continue
+            cand_u.append(tu)
+            cand_r.append(torch.full_like(tu, r))
+            cand_k.append(cross[:, tu].sum(dim=0))
+            ri, ru = torch.nonzero(cross, as_tuple=True)
+            row_u.append(ru)
+            row_r.append(torch.full_like(ru, r))
+            row_i.append(ri + int(rp[r]))
+        cand_u = torch.cat(cand_u).cpu().numpy(); cand_r = torch.cat(cand_r).cpu().numpy(); cand_k = torch.cat(cand_k).cpu().numpy()
+        row_u = torch.cat(row_u).cpu().numpy(); row_r = torch.cat(row_r).cpu().numpy(); row_i = torch.cat(row_i).cpu().numpy()
+        o = np.lexsort((cand_r, cand_u)); cand_u, cand_r, cand_k = cand_u[o], cand_r[o], cand_k[o]
+        o = np.lexsort((row_i, row_r, row_u)); row_u, row_i = row_u[o], row_i[o]
+        cstart = np.searchsorted(cand_u, np.arange(und.numel() + 1))
+        rstart = np.concatenate(([0], np.cumsum(cand_k)))            # rows of candidate j: row_i[rstart[j]:rstart[j + 1]]
+        codes = np.full(und.numel(), -2, np.int64)
+        for u in range(und.numel()):
+            ints = [0]
+            for j in range(cstart[u], cstart[u + 1]):
+                k = int(cand_k[j])
+                ints += [int(cand_r[j]), k] + row_i[rstart[j]:rstart[j + 1]].tolist()
+                ints[0] += 1
+                if k == 0:
+                    break
+            if len(ints) <= cls.LIST_MAX_INTS:
+                codes[u] = -3 - len(pool)
+                pool += ints
+        sure = sure.clone()
+        sure[und] = torch.as_tensor(codes, device=dev).to(torch.int32)
+        return torch.as_tensor(np.array(pool, np.int32), device=dev), sure, float((codes <= -3).sum()) / sure.numel()
 
     def locate(self, X, nu=None, tol=1.e-7, use_boxes=True, use_grid=True, use_sure=True):
         """Batched look-up: X [B x p] -> device tensors (idx int32 [B], u [B x nu], V [B]); no synchronisation.
@@ -469,7 +546,9 @@ class ExplicitSolution(object):
                                             _hip.ptr(d['box']) if (use_boxes and tol <= 1.e-7) else None,
                                             _hip.ptr(d['grid_geom']) if grid else None, t['grid']['n'] if grid else 0,
                                             _hip.ptr(d['grid_masks']) if grid else None,
-                                            _hip.ptr(d['grid_sure']) if (grid and use_sure) else None, _hip.ptr(X), B, float(tol),
+                                            _hip.ptr(d['grid_sure']) if (grid and use_sure) else None,
+                                            _hip.ptr(d['grid_lists']) if (grid and use_sure) else None,
+                                            int(t['grid']['needs_scan']) if (grid and use_sure) else 1, _hip.ptr(X), B, float(tol),
                                             _hip.ptr(idx), _hip.ptr(u), _hip.ptr(V), _hip.stream_ptr()))
         return idx, u, V
 

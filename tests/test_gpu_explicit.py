@@ -344,7 +344,7 @@ def test_nan_points_and_empty_table(nb, oracle):
     oV = torch.zeros(1000, dtype=torch.float64, device='cuda')
     rp = torch.zeros(1, dtype=torch.int32, device='cuda')
     _hip.check(lib.pympc_point_location(0, 0, 2, 1, None, None, _hip.ptr(rp), None, None, None, None, None, None, None, 0, None,
-                                        None, _hip.ptr(Xd), 1000, 1e-7, _hip.ptr(oi), _hip.ptr(ou), _hip.ptr(oV), _hip.stream_ptr()))
+                                        None, None, 1, _hip.ptr(Xd), 1000, 1e-7, _hip.ptr(oi), _hip.ptr(ou), _hip.ptr(oV), _hip.stream_ptr()))
     torch.cuda.synchronize()
     assert bool((oi == -1).all()) and bool(torch.isnan(oV).all()) and bool(torch.isnan(ou).all())
 

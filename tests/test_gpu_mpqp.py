@@ -253,6 +253,34 @@ def test_batch_size_does_not_change_decisions():
     assert many.sum() > 500                     # the states the two launches finish in different kernels
 
 
+def test_chunk_counter_does_not_change_results():
+    """From 524 288 states on, with a certificate table, the workgroups of the Gram-form and Lawson-Hanson kernels draw
+    their states in chunks from a device counter instead of fixed shares (launch policy, pympc_hip_tune
+    "dynamic_chunks").  Every state is still solved once, by the same code: outputs bitwise the same, nothing left
+    pending, also when the same table is used again right away (the screening kernel clears the counters)."""
+    import torch
+    from pympc_amd import _hip
+    model = golden("c2_model")
+    x_max = model["x_max"]
+    B = 600000
+    X = torch.as_tensor(np.random.RandomState(5).uniform(-0.5 * x_max, 0.5 * x_max, (B, 4))).cuda()
+    prep = _prepared(model)
+    outs = []
+    for dyn in (1, 0, 1, 1):
+        with _hip.tuned(dynamic_chunks=dyn):
+            if dyn == 0 or len(outs) < 2:
+                prep.reset_cuts(hard=True)
+            r = prep.solve_batch(X, use_cuts=True, want_mult=False)
+            outs.append(tuple(r.t[k].clone() for k in ("status", "argmin", "min", "active_bits")))
+    st = outs[0][0].cpu().numpy()
+    assert set(np.unique(st)) <= {0, 1} and (st == 0).sum() > 100000 and (st == 1).sum() > 100000
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0])
+        ok = outs[0][0] == 0
+        assert torch.equal(o[1][ok], outs[0][1][ok]) and torch.equal(o[2][ok], outs[0][2][ok])
+        assert torch.equal(o[3][ok], outs[0][3][ok])
+
+
 @pytest.mark.parametrize("scale,count", [(0.3, 40000), (0.6, 20000)])
 def test_screened_states_vs_per_problem_kernel(scale, count):
     """The shared-matrix launch finishes most states in the screening pass (no active constraint; ONE active

@@ -19,7 +19,8 @@ model = dict(np.load(os.path.join(ROOT, "tests", "golden", "c2_model.npz")))
 prep = PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model["fx"], float(model["g"]),
                     model["Au"], model["Ax"], model["b"])
 X = torch.as_tensor(np.random.RandomState(0).uniform(-scale * model["x_max"], scale * model["x_max"], (B, 4))).cuda()
-out = _alloc_outputs(B, 1, model["Au"].shape[0], X.device, want_mult=False, want_active=True, want_iters=False)
+out = _alloc_outputs(B, 1, model["Au"].shape[0], X.device, want_mult=False, want_active=os.environ.get("PYMPC_NO_ACTIVE") is None,
+                     want_iters=False)
 cuts = sys.argv[4] if len(sys.argv) > 4 else "cold"
 for _ in range(launches):
     if cuts == "cold":

@@ -32,7 +32,7 @@
 
 namespace pympc {
 
-constexpr int kLpNMax = 32;         // variables (rows of the dual system; one lane per row, LDS 2 x 32 x 33 doubles)
+constexpr int kLpNMax = 64;         // variables (rows of the dual system; one lane per row, LDS 2 x n x (n | 1) doubles)
 constexpr int kLpMMax = 1 << 18;    // rows of A (working-set bitmap of m bits in LDS)
 constexpr double kLpFeasTol = 1e-9; // phase 2: row j is violated when a_j x > b_j + kLpFeasTol max(1, |b_j|)
 constexpr int kLpRejMax = 32;       // rejected candidates remembered per outer iteration of phase 1

@@ -285,7 +285,7 @@ class Polyhedron(object):
         """
         Bounded iff ker(A) = 0 and the polyhedron has no recession direction (polyhedron.py:528-576).  The reference
         decides the second part with Stiemke's alternative, an LP with one variable per ROW of A (some y >= 1 with
-        A'y = 0); that LP is used here while it fits the LP kernel (rows <= 32 variables).  Beyond that the same decision
+        A'y = 0); that LP is used here while it fits the LP kernel (rows <= 64 variables).  Beyond that the same decision
         is taken in the primal space: a non-empty polyhedron is bounded iff the 2 dim LPs max +-x_i over it all have an
         optimum (one batched launch against the shared constraint matrix).
         """

@@ -164,6 +164,36 @@ def test_random_lps_vs_oracle(oracle):
     assert n_solv > 50
 
 
+@pytest.mark.parametrize("n", [33, 48, 64])
+def test_many_variables_vs_oracle(oracle, n):
+    """LPs with more than 32 variables (up to the kernel's 64: one lane per row of the dual system), against the oracle's
+    restatement of pnnls.linear_program: boxes cut by random rows (bounded, generic), the same with a row that makes
+    them infeasible, and an unbounded one."""
+    rng = np.random.RandomState(100 + n)
+    lp = _lp()
+    for t in range(6):
+        m_extra = 20 + 10 * t
+        A = np.vstack((np.eye(n), -np.eye(n), rng.randn(m_extra, n)))
+        b = np.concatenate((np.ones(2 * n), 1. + rng.rand(m_extra)))
+        f = rng.randn(n)
+        if t == 4:                                   # infeasible: x_0 <= -2 against x_0 >= -1
+            A = np.vstack((A, np.eye(n)[:1])); b = np.concatenate((b, [-2.]))
+        if t == 5:                                   # unbounded: no bound along -f
+            A = A[2 * n:]; b = b[2 * n:]
+            A = A[A.dot(f) > 0]; b = b[:A.shape[0]]
+        ref = oracle.linear_program(f, A, b)
+        sol = lp(f, A, b)
+        assert (sol['min'] is None) == (ref['min'] is None), (n, t)
+        if t >= 4:
+            assert ref['min'] is None
+            continue
+        assert ref['min'] is not None
+        assert abs(sol['min'] - ref['min']) < 1e-6 * max(1., abs(ref['min'])), (n, t)
+        assert np.allclose(sol['argmin'], ref['argmin'], rtol=1e-6, atol=1e-6), (n, t)
+        assert np.allclose(sol['multiplier_inequality'], ref['multiplier_inequality'], rtol=1e-6, atol=1e-6), (n, t)
+        assert sol['active_set'] == ref['active_set'], (n, t)
+
+
 def test_lp_batch_shared_matrix_relaxation(oracle):
     """The minimal_facets batch form: shared A, shared b, per-problem relaxed row (polyhedron.py:439-441)."""
     from pympc_amd.optimization.solvers.hip_lp import linear_program_batch

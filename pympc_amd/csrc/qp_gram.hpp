@@ -40,10 +40,12 @@ constexpr double kGramGammaMin = 1e-8;  // squared residual below which the stat
 __host__ __device__ inline size_t gram_lds_doubles(int p, const WsLayout &L) { return (size_t)(p + 2) * L.mp + (L.total - L.u0); }
 
 // One state.  cnl / m0l / Gml / tab: LDS copies (tab indexed like the workspace: tab[L.u0 ...]).  Returns with the
-// outputs written, or with nothing written (status stays pending).
+// outputs written, or with nothing written (status stays pending).  warm >= 0: c0 | c1 << 11, the two passive columns on
+// which the lane path left the state (both coefficients positive, a third column entering): the first two outer iterations
+// -- two arg-max sweeps, two borderings, three rows of Gr -- are not repeated; H is built by the same two bordering steps.
 template <int MT>
 __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long prob, const double *cnl, const double *m0l,
-                                                const double *Gml, const double *tab)
+                                                const double *Gml, const double *tab, int warm)
 {
     constexpr int mp = 64 * MT;
     constexpr int RW = 2;   // rows of Gr in flight in the sweep
@@ -86,9 +88,6 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
                 }
         }
     }
-#pragma unroll
-    for (int s = 0; s < MT; ++s) w[s] = (col_of(lane, s) >= m) ? -1.0 : -mv[s];
-
     PYMPC_TICK(0)
     uint32_t inP = 0;
     int k = 0, iter = 0, outer = 0;
@@ -140,7 +139,72 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
         return piv > 0.0;
     };
 
+    if (warm >= 0) {
+        const int c0 = warm & 2047, c1 = warm >> 11;
+        double ms0 = mv[0], ms1 = mv[0];
+#pragma unroll
+        for (int s = 1; s < MT; ++s) {
+            ms0 = (s == slot_of(c0)) ? mv[s] : ms0;
+            ms1 = (s == slot_of(c1)) ? mv[s] : ms1;
+        }
+        const double mc0 = lane_f64(ms0, lane_of(c0)), mc1 = lane_f64(ms1, lane_of(c1));
+        const double g00 = cnl[c0], g11 = cnl[c1], g01 = P.gram[(size_t)c1 * mp + c0];
+        // (the two bordering steps of the loop below, written out: k = 0 -> 1 -> 2)
+        const double i0 = fast_div(1.0, g00);
+        const double h = i0 * g01;
+        const double sch = g11 - g01 * h;
+        if (sch > kGramPivotMin * g11) {
+            const double si = fast_div(1.0, sch), hs = h * si;
+            if (lane == 0) { Hrow[0] = fma(hs, h, i0); Hrow[1] = -hs; Pl = c0; mPl = mc0; }
+            if (lane == 1) { Hrow[0] = -h * si; Hrow[1] = si; Pl = c1; mPl = mc1; }
+            if (lane == lane_of(c0)) inP |= 1u << slot_of(c0);
+            if (lane == lane_of(c1)) inP |= 1u << slot_of(c1);
+            k = 2;
+            const double zl = gram_solve();
+            const bool fine = !(lane < 2) || (zl > 0.0 && fabs(zl) < kGramMaxCoeff);
+            if (__ballot(!fine) == 0ull && gam > kGramGammaMin) {
+                if (lane < 2) yl = zl;
+                outer = 2;
+                iter = 2;
+            } else {   // (not what the lane path saw, to rounding: from nothing, then)
+                k = 0; inP = 0; Pl = -1; yl = 0.0; mPl = 0.0; gam = 1.0; gz = 0.0; gtq = 0.0;
+#pragma unroll
+                for (int b = 0; b < kGramK; ++b) Hrow[b] = 0.0;
+            }
+        }
+    }
+
     for (;;) {
+        // ---------------- dual sweep  w = -gam m - sum_l y_l Gr[P_l][:]   (nothing passive yet: w = -m)
+        {
+            const double ng = -gam;
+#pragma unroll
+            for (int s = 0; s < MT; ++s) w[s] = ng * mv[s];
+            for (int l0 = 0; l0 < k; l0 += RW) {
+                double2 a[RW][MT / 2];
+                double yv[RW];
+#pragma unroll
+                for (int u = 0; u < RW; ++u) {
+                    const int l = min(l0 + u, k - 1);
+                    const double yy = lane_f64(yl, l);
+                    yv[u] = (l0 + u < k) ? -yy : 0.0;
+                    const double2 *gr = reinterpret_cast<const double2 *>(P.gram + (size_t)lane_i32(Pl, l) * mp) + lane;
+#pragma unroll
+                    for (int h = 0; h < MT / 2; ++h) a[u][h] = gr[64 * h];
+                }
+#pragma unroll
+                for (int u = 0; u < RW; ++u)
+#pragma unroll
+                    for (int h = 0; h < MT / 2; ++h) {
+                        w[2 * h] = fma(yv[u], a[u][h].x, w[2 * h]);
+                        w[2 * h + 1] = fma(yv[u], a[u][h].y, w[2 * h + 1]);
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < MT; ++s)
+                if (col_of(lane, s) >= m || ((inP >> s) & 1u)) w[s] = -1.0;
+        }
+        PYMPC_TICK(5)
         // ---------------- the column of largest guaranteed decrease (the rule of qp_wave_solve), tested in Gram form
         bool accepted = false, stale = false;   // stale: gz / gtq / gam belong to a trial set whose new column was refused
         int j = -1, jl = 0, js = 0;
@@ -250,35 +314,6 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
         }
         if (giveup) break;
         PYMPC_TICK(4)
-
-        // ---------------- dual sweep  w = -gam m - sum_l y_l Gr[P_l][:]
-        const double ng = -gam;
-#pragma unroll
-        for (int s = 0; s < MT; ++s) w[s] = ng * mv[s];
-        for (int l0 = 0; l0 < k; l0 += RW) {
-            double2 a[RW][MT / 2];
-            double yv[RW];
-#pragma unroll
-            for (int u = 0; u < RW; ++u) {
-                const int l = min(l0 + u, k - 1);
-                const double yy = lane_f64(yl, l);
-                yv[u] = (l0 + u < k) ? -yy : 0.0;
-                const double2 *gr = reinterpret_cast<const double2 *>(P.gram + (size_t)lane_i32(Pl, l) * mp) + lane;
-#pragma unroll
-                for (int h = 0; h < MT / 2; ++h) a[u][h] = gr[64 * h];
-            }
-#pragma unroll
-            for (int u = 0; u < RW; ++u)
-#pragma unroll
-                for (int h = 0; h < MT / 2; ++h) {
-                    w[2 * h] = fma(yv[u], a[u][h].x, w[2 * h]);
-                    w[2 * h + 1] = fma(yv[u], a[u][h].y, w[2 * h + 1]);
-                }
-        }
-#pragma unroll
-        for (int s = 0; s < MT; ++s)
-            if (col_of(lane, s) >= m || ((inP >> s) & 1u)) w[s] = -1.0;
-        PYMPC_TICK(5)
     }
     if (giveup) return;
     PYMPC_TICK(6)
@@ -387,12 +422,12 @@ __global__ void __launch_bounds__(kGramThreads) __attribute__((amdgpu_waves_per_
             if (t >= mine) break;
             base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
         }
-        const bool pend = lane < S && base + lane < P.B && P.status[base + lane] == kStatusPending;
-        unsigned long long todo = __ballot(pend);
+        const int st = (lane < S && base + lane < P.B) ? P.status[base + lane] : 0;
+        unsigned long long todo = __ballot(status_is_pending(st));
         while (todo != 0ull) {
             const int b = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
-            gram_wave_solve<MT>(P, base + b, cnl, m0l, Gml, tabl - L.u0);
+            gram_wave_solve<MT>(P, base + b, cnl, m0l, Gml, tabl - L.u0, status_warm_columns(lane_i32(st, b)));
         }
     }
 }

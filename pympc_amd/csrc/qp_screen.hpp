@@ -255,7 +255,8 @@ __device__ __forceinline__ int screen_stage(const SolveParams &P, cdouble_ptr m0
         jnext = jb;
         return kScreenNext;
     }
-    P.status[prob] = kStatusPending;
+    // (a last stage of two columns that is fine but not optimal: the passive set travels with the state)
+    P.status[prob] = (LAST && K == 2 && ok && more) ? status_pending_warm(cols[0], cols[K - 1]) : kStatusPending;
     return kScreenPunt;
 }
 

@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
                 base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
             }
             bool pend = lane < S && base + lane < P.B;
-            if (P.screened && pend) pend = (P.status[base + lane] == kStatusPending);
+            if (P.screened && pend) pend = status_is_pending(P.status[base + lane]);
             unsigned long long todo = __ballot(pend);
             while (todo != 0ull) {
                 const int b = __ffsll((long long)todo) - 1;

@@ -28,6 +28,11 @@ constexpr int kStatusInfeasible = 1;
 constexpr int kStatusMaxIter = 3;
 constexpr int kStatusNotPD = 4;
 constexpr int kStatusPending = -1;   // between the screening pass and the solve kernel only: never returned
+// ... and every value below it: "pending, and the lane path ended on the passive columns (c0, c1), both with a positive
+// coefficient, with a third column entering": the Gram-form kernel starts from that set instead of from nothing
+__host__ __device__ inline int status_pending_warm(int c0, int c1) { return -2 - (c0 | (c1 << 11)); }   // columns < 2048 = kMMax
+__host__ __device__ inline bool status_is_pending(int st) { return st < 0; }
+__host__ __device__ inline int status_warm_columns(int st) { return st <= -2 ? -2 - st : -1; }          // c0 | c1 << 11, or -1
 constexpr double kGramDiag = 1e300;  // diagonal of the stored Gram matrix (the true one is cn): see qp_screen.hpp
 
 constexpr int kNMax = 63;    // variables: R = n + 1 <= 64 rows, one lane per row

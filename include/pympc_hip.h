@@ -96,6 +96,10 @@ int pympc_mpqp_prepare(int n, int m, int p, const double *Huu, const double *Hux
  *   vmin    [B]           lifted optimal value (parametric_programs.py:177)
  *   mult    [B x m]       multiplier_inequality (pnnls.py:232)
  *   active  [B x ceil(m/32)] uint32 bit j of word j/32 set iff multiplier j > tol (pnnls.py:235)
+ *           (in a launch of >= 8192 states the kernels also use a state's active words as hand-over space while it is
+ *           pending: a state the Gram-form kernel leaves at 8 passive columns starts the Lawson-Hanson kernel from those
+ *           columns when `active` is given and from nothing when it is NULL -- the same result to rounding (1e-8), the
+ *           same decisions, but not the same last bits)
  *   status  [B]           PYMPC_OPTIMAL / PYMPC_INFEASIBLE / PYMPC_MAXITER
  *   iters   [B x 2]       (outer, inner) NNLS iteration counters (roofline accounting)
  */

@@ -254,14 +254,14 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
             // persistent workgroups, two per CU, each walking over whole tiles of states (qp_screen.hpp); the grid is
             // evened out so that every workgroup gets the same number of tiles (+- 1)
             long long tile = (long long)kScreenThreads * (p <= 4 ? 2 : 1);   // = kScreenThreads * screen_states_per_lane<p>()
-            if (P.B < 2LL * ncu * tile) {   // a small batch: smaller tiles (whole wavefronts), so that it still spreads over the chip
-                const long long per = (P.B + 2LL * ncu - 1) / (2LL * ncu);
+            if (P.B < (long long)kScreenWgPerCu * ncu * tile) {   // a small batch: smaller tiles (whole wavefronts), so that it still spreads over the chip
+                const long long per = (P.B + (long long)kScreenWgPerCu * ncu - 1) / ((long long)kScreenWgPerCu * ncu);
                 const long long t64 = (per + 63) / 64 * 64;
                 if (t64 < tile) tile = t64 < 64 ? 64 : t64;
             }
             P.screen_tile = (int)tile;
             const long long ntile = (P.B + tile - 1) / tile;
-            const long long rounds = (ntile + 2LL * ncu - 1) / (2LL * ncu);
+            const long long rounds = (ntile + (long long)kScreenWgPerCu * ncu - 1) / ((long long)kScreenWgPerCu * ncu);
             const long long sg = (ntile + rounds - 1) / rounds;
 #define PYMPC_SCREEN_CASE(PD) case PD: hipLaunchKernelGGL(mpqp_screen_kernel<PD>, dim3((unsigned)sg), dim3(kScreenThreads), 0, st, P); break;
             switch (p) {

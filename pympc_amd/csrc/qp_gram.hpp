@@ -32,6 +32,7 @@ namespace pympc {
 constexpr int kGramThreads = 768;       // one workgroup per CU: 12 waves (3 per SIMD, 168 VGPRs: nothing spills) draw from one pool of slices
 constexpr int kGramSlice = 16;           // states per ticket of a wave (<= 64)
 constexpr int kGramK = 8;               // passive columns up to which a state stays in this kernel (<= 8: wsum8)
+static_assert(kGramK == kStatusSetColumns, "the hand-over format of kStatusPendingSet holds kGramK columns");
 constexpr double kGramPivotMin = 1e-6;  // relative Schur complement below which a column counts as nearly dependent
 constexpr double kGramGammaMin = 1e-8;  // squared residual below which the state is left to the factorised solve
 
@@ -98,7 +99,7 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
     for (int b = 0; b < kGramK; ++b) Hrow[b] = 0.0;
     double gam = 1.0, gz = 0.0, gtq = 0.0;
     const int itmax = P.itmax_factor * m;
-    bool giveup = false;
+    bool giveup = false, handoff = false;
 
     // z = H m_P, t, gam; returns the candidate coefficients -z gam (lanes < k)
     auto gram_solve = [&]() __attribute__((always_inline)) -> double {
@@ -239,7 +240,11 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
                 if (stale) (void)gram_solve();   // ... whose solution the refused trials overwrote
                 break;
             }
-            if (k >= kGramK || k + 1 >= R || k + 1 >= m) { giveup = true; break; }
+            if (k >= kGramK || k + 1 >= R || k + 1 >= m) {
+                giveup = true;
+                handoff = k >= kGramK;   // (a consistent passive set: the factorised solve can start from it)
+                break;
+            }
             j = 1023 - (int)(__double_as_longlong(gmax) & 0x3ffLL);
             jl = lane_of(j);
             js = slot_of(j);
@@ -315,7 +320,17 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
         if (giveup) break;
         PYMPC_TICK(4)
     }
-    if (giveup) return;
+    if (giveup) {
+        // the passive set travels with the state (kStatusPendingSet): its kGramK columns in the order they entered, two per
+        // word of the state's active-set words
+        const int nwords = (m + 31) / 32;
+        if (handoff && P.active && k == kGramK && nwords >= kGramK / 2) {
+            const int lo = __shfl(Pl, 2 * (lane & 31)), hi = __shfl(Pl, 2 * (lane & 31) + 1);
+            if (lane < kGramK / 2) P.active[prob * nwords + lane] = (uint32_t)lo | ((uint32_t)hi << 16);
+            if (lane == 0) P.status[prob] = kStatusPendingSet;
+        }
+        return;
+    }
     PYMPC_TICK(6)
 
     // ---------------- outputs (pnnls.py:230-239, parametric_programs.py:176-177): optimal with multipliers -z

@@ -36,7 +36,14 @@
 
 namespace pympc {
 
-constexpr int kScreenThreads = 512;
+#ifndef PYMPC_SCREEN_THREADS
+#define PYMPC_SCREEN_THREADS 512
+#endif
+#ifndef PYMPC_SCREEN_WG_PER_CU
+#define PYMPC_SCREEN_WG_PER_CU 2
+#endif
+constexpr int kScreenThreads = PYMPC_SCREEN_THREADS;
+constexpr int kScreenWgPerCu = PYMPC_SCREEN_WG_PER_CU;   // persistent workgroups per CU (x kScreenThreads / 256 = waves per SIMD)
 #ifndef PYMPC_SCREEN_U0
 #define PYMPC_SCREEN_U0 2
 #endif
@@ -280,7 +287,11 @@ __device__ __forceinline__ void screen_push(bool push, int *cnt, int *qid, int (
 }
 
 template <int PD>
-__global__ void __launch_bounds__(kScreenThreads) mpqp_screen_kernel(SolveParams P)
+__global__ void __launch_bounds__(kScreenThreads)
+#ifdef PYMPC_SCREEN_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(PYMPC_SCREEN_WAVES_PER_EU, PYMPC_SCREEN_WAVES_PER_EU)))
+#endif
+mpqp_screen_kernel(SolveParams P)
 {
     constexpr int S = screen_states_per_lane<PD>();
     constexpr int U0 = kScreenU0;   // columns per step of the stage-0 sweep

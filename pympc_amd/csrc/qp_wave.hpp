@@ -238,7 +238,7 @@ template <int MT>
 __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ Mt, int mtp, const double *__restrict__ m0,
                               const double *__restrict__ Gm, const double *__restrict__ tab,
                               const double *__restrict__ wsg, long long prob, double *wl, bool prepared_ok,
-                              const double *__restrict__ cnorm)
+                              const double *__restrict__ cnorm, bool warmset = false)
 {
     constexpr int mp = 64 * MT;
     constexpr int SW = MT <= 8 ? 4 : (MT <= 16 ? 2 : 1);   // rows of the dual sweep in flight (MT * SW loads)
@@ -322,6 +322,56 @@ __device__ void qp_wave_solve(const SolveParams &P, const double *__restrict__ M
 #ifdef PYMPC_COUNT_TRIALS
     int trials = 0;   // debug build: candidate tests, reported in place of the inner-iteration counter
 #endif
+
+    // ---- a state the Gram-form kernel left at kStatusSetColumns passive columns (kStatusPendingSet): factorise that set,
+    // column by column in the order they entered (the very sequence of updates this kernel would have gone through),
+    // instead of finding it again with eight sweeps and arg-max searches.  Anything unexpected (a dependent column, a
+    // coefficient that does not come out positive) and the state starts from nothing, as every other state does.
+    if (warmset && P.active && status == kStatusOptimal) {
+        const int nwords = (m + 31) / 32;
+        const uint32_t myword = (lane < kStatusSetColumns / 2) ? P.active[prob * nwords + lane] : 0u;
+        bool good = true;
+        for (int l = 0; l < kStatusSetColumns; ++l) {
+            const uint32_t word = (uint32_t)lane_i32((int)myword, l >> 1);
+            const int jw = (int)((l & 1) ? (word >> 16) : (word & 0xffffu));
+            if (jw >= m || k + 1 >= R) { good = false; break; }
+            const int jwl = lane_of(jw), jws = slot_of(jw);
+            if (lane_i32((int)((inP >> jws) & 1u), jwl) != 0) { good = false; break; }   // (twice the same column: not a set)
+            double mvsel = mv[0];
+#pragma unroll
+            for (int s = 1; s < MT; ++s) mvsel = (s == jws) ? mv[s] : mvsel;
+            const double mjw = lane_f64(mvsel, jwl);
+            double ai = 0.0;
+            if (lane < n) ai = -Mt[lane * mtp + jw];
+            else if (lane == n) ai = -mjw;
+            const QrTrial tw = qr_trial(F, k, ai, !qt_ready);
+            if (!tw.independent) { good = false; break; }
+            if (!qt_ready) {
+                qr_add_first(F, tw);
+                qt_ready = true;
+            } else {
+                qr_add(F, k, tw);
+            }
+            if (lane == k) { Pl = jw; yl = 0.0; mPl = mjw; }
+            if (lane == jwl) inP |= (1u << jws);
+            ++k;
+        }
+        if (good && k > 0) {
+            const double zl = qr_coeff(F, k);
+            if (__ballot(lane < k && !(zl > 0.0)) == 0ull) {
+                if (lane < k) yl = zl;
+                outer = k;
+                iter = k;
+            } else {
+                good = false;
+            }
+        }
+        if (!good) {
+            k = 0; inP = 0; Pl = -1; yl = 0.0; mPl = 0.0; qt_ready = false;
+            if (lane < R) F.cv[lane] = (lane == n) ? 1.0 : 0.0;
+            wave_sync_lds();
+        }
+    }
 
     PYMPC_TICK(0)
 
@@ -744,13 +794,17 @@ __global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(So
                 base = ((long long)blockIdx.x + (long long)t * gridDim.x) * S;
             }
             bool pend = lane < S && base + lane < P.B;
-            if (P.screened && pend) pend = status_is_pending(P.status[base + lane]);
+            int st = kStatusPending;
+            if (P.screened && pend) {
+                st = P.status[base + lane];
+                pend = status_is_pending(st);
+            }
             unsigned long long todo = __ballot(pend);
             while (todo != 0ull) {
                 const int b = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;
                 qp_wave_solve<MT>(P, lds, S_.mtp, P.ws + P.L.m0, P.ws + P.L.Gm, lds + S_.tab - P.L.u0, P.ws, base + b, wl, shared_ok,
-                                  lds + S_.cn);
+                                  lds + S_.cn, lane_i32(st, b) == kStatusPendingSet);
             }
         }
     } else {

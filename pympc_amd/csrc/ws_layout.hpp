@@ -32,7 +32,12 @@ constexpr int kStatusPending = -1;   // between the screening pass and the solve
 // coefficient, with a third column entering": the Gram-form kernel starts from that set instead of from nothing
 __host__ __device__ inline int status_pending_warm(int c0, int c1) { return -2 - (c0 | (c1 << 11)); }   // columns < 2048 = kMMax
 __host__ __device__ inline bool status_is_pending(int st) { return st < 0; }
-__host__ __device__ inline int status_warm_columns(int st) { return st <= -2 ? -2 - st : -1; }          // c0 | c1 << 11, or -1
+// ... and one more: "pending, the Gram-form kernel stopped at kGramK passive columns (all coefficients positive, another
+// column entering) and left those columns, in the order they entered, in the first words of the state's active-set
+// output (two 16-bit indices per word)": the Lawson-Hanson kernel factorises them in that order and goes on from there
+constexpr int kStatusPendingSet = -2 - (1 << 30);
+constexpr int kStatusSetColumns = 8;   // = kGramK (qp_gram.hpp)
+__host__ __device__ inline int status_warm_columns(int st) { return (st <= -2 && st != kStatusPendingSet) ? -2 - st : -1; }   // c0 | c1 << 11, or -1
 constexpr double kGramDiag = 1e300;  // diagonal of the stored Gram matrix (the true one is cn): see qp_screen.hpp
 
 constexpr int kNMax = 63;    // variables: R = n + 1 <= 64 rows, one lane per row

@@ -232,7 +232,10 @@ def test_bench_configuration_vs_oracle(oracle, scale):
 def test_batch_size_does_not_change_decisions():
     """The Gram-form kernel only runs from 8192 states on (launch policy): states with 3..8 active constraints are then
     finished by another kernel than in a small batch.  Decisions must not depend on that: statuses and active bits of
-    the same states identical whichever kernel finishes them, values equal to rounding."""
+    the same states identical whichever kernel finishes them, values equal to rounding.  (States with more than 8 active
+    constraints start the Lawson-Hanson kernel from the Gram-form kernel's 8 columns in the large batch and from nothing
+    in the small one: the same least-squares problems through another history of updates, 1e-8 instead of the 1e-9 that
+    holds between the two kernels' own results; the path's tolerance is 1e-6.)"""
     from pympc_amd import _hip
     model = golden("c2_model")
     x_max = model["x_max"]
@@ -247,8 +250,8 @@ def test_batch_size_does_not_change_decisions():
     edge = ((np.abs(lam - 1e-7) < 1e-9 * np.maximum(1.0, np.abs(lam).max(axis=1, keepdims=True))) & (lam != 0.0)).any(axis=1)
     assert edge.sum() <= 3
     assert np.array_equal(big.active_mask()[ok][~edge], small.active_mask()[ok][~edge])
-    assert _rel(big.numpy("argmin")[ok], small.numpy("argmin")[ok]) < 1e-9
-    assert _rel(big.numpy("min")[ok], small.numpy("min")[ok]) < 1e-9
+    assert _rel(big.numpy("argmin")[ok], small.numpy("argmin")[ok]) < 1e-8
+    assert _rel(big.numpy("min")[ok], small.numpy("min")[ok]) < 1e-8
     many = ok & (small.numpy("iters")[:, 0] >= 3)
     assert many.sum() > 500                     # the states the two launches finish in different kernels
 

@@ -62,6 +62,9 @@ const char *pympc_hip_last_error(void);
  *                        Lawson-Hanson kernels draw chunks of 256 states from a device counter per kernel (in the table's
  *                        header) and share them out to their waves through LDS; 0: a fixed share of interleaved slices
  *                        per workgroup.  Which wave solves a state never changes its result
+ *   "prepare_wave"       1 (default): batches of >= 1024 problems with up to 16 variables are factorised one wavefront per
+ *                        problem with the constraint rows in registers; 0: the row-tile kernel.  Same sums in the same
+ *                        order: bitwise the same workspace
  * Process-wide, read at launch time; not meant to be changed while other threads launch.
  */
 int pympc_hip_tune(const char *key, long long value, long long *previous);

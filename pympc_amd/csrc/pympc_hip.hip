@@ -65,6 +65,7 @@ struct Tune {
     std::atomic<long long> learn_min_batch{131072};              // certificate-learning pre-pass from this many states
     std::atomic<long long> nnls_itmax_factor{3};                 // NNLS iteration limit = factor * columns (scipy: 3)
     std::atomic<long long> reserved_cus{0};                      // compute units the persistent launches leave free
+    std::atomic<long long> prepare_wave{1};                      // 1: qp_prepare_wave_kernel for batches of small problems, 0: the tile kernel
     std::atomic<long long> dynamic_chunks{1};                    // 1: chunks of states from a device counter (Gram / solve kernels), 0: static shares
 };
 Tune g_tune;
@@ -143,7 +144,7 @@ int launch_solve(int mt, const SolveParams &P, int nwaves, size_t lds_bytes, lon
 
 // Launch geometry of the per-problem prepare workgroup: one thread per constraint row of a tile (up to 256 rows,
 // fewer when two row tiles of that size would not fit beside the factor matrices in ~96 KiB of LDS).
-struct PrepGeom { int threads, tile_rows; size_t lds_bytes; };
+struct PrepGeom { int threads, tile_rows; size_t lds_bytes; int wave_nn; };   // wave_nn > 0: qp_prepare_wave_kernel<wave_nn>
 constexpr long long kPrepSmallBatch = 1024;
 PrepGeom prep_geom(int n, int m, int p, long long B = 1)
 {
@@ -156,7 +157,32 @@ PrepGeom prep_geom(int n, int m, int p, long long B = 1)
     G.tile_rows = tr;
     G.threads = (n * n >= 1024 && tr < 256) ? 256 : tr;
     G.lds_bytes = prep_lds_doubles(n, p, tr) * 8;
+    G.wave_nn = 0;
+    // many problems of up to 16 variables: one wavefront per problem with its constraint rows in registers
+    // (qp_prepare_wave_kernel: no row tiles in LDS, so the wavefronts per CU are not limited by it)
+    if (B >= kPrepSmallBatch && n <= 16 && g_tune.prepare_wave.load() != 0) {
+        G.wave_nn = (n + 3) / 4 * 4;
+        G.threads = 64;
+        G.tile_rows = 64;
+        G.lds_bytes = prep_wave_lds_doubles(n, p) * 8;
+    }
     return G;
+}
+
+int launch_prepare(const PrepGeom &G, const PrepParams &Q, long long B, hipStream_t st)
+{
+    switch (G.wave_nn) {
+#define PYMPC_PREP_CASE(NN)                                                                                   \
+    case NN:                                                                                                  \
+        if (int rc = allow_lds(qp_prepare_wave_kernel<NN>, G.lds_bytes)) return rc;                           \
+        hipLaunchKernelGGL(qp_prepare_wave_kernel<NN>, dim3((unsigned)B), dim3(64), G.lds_bytes, st, Q);      \
+        return check_launch("qp_prepare_wave_kernel");
+        PYMPC_PREP_CASE(4) PYMPC_PREP_CASE(8) PYMPC_PREP_CASE(12) PYMPC_PREP_CASE(16)
+#undef PYMPC_PREP_CASE
+    }
+    if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
+    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, st, Q);
+    return check_launch("qp_prepare_kernel");
 }
 
 int check_shape(int n, int m, int p)
@@ -367,6 +393,7 @@ int pympc_hip_tune(const char *key, long long value, long long *previous)
         {"nnls_itmax_factor", &g_tune.nnls_itmax_factor, 0, 1000},
         {"reserved_cus", &g_tune.reserved_cus, 0, 128},
         {"dynamic_chunks", &g_tune.dynamic_chunks, 0, 1},
+        {"prepare_wave", &g_tune.prepare_wave, 0, 1},
     };
     for (auto &k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -628,9 +655,7 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
     const PrepGeom G = prep_geom(n, m, Q.p, B);
     if (int rc = check_prep(G, n, m, Q.p)) return rc;
     Q.tile_rows = G.tile_rows;
-    if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
-    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);
-    if (int rc = check_launch("qp_prepare_kernel")) return rc;
+    if (int rc = launch_prepare(G, Q, B, (hipStream_t)stream)) return rc;
     SolveParams P;
     memset(&P, 0, sizeof(P));
     P.ws = ws; P.ws_stride = (long long)L.total; P.ws_status = ws_status;
@@ -677,9 +702,7 @@ int pympc_mpqp_multi_solve(int n, int m, int p, int64_t B, const double *Huu, co
     const PrepGeom G = prep_geom(n, m, Q.p, B);
     if (int rc = check_prep(G, n, m, Q.p)) return rc;
     Q.tile_rows = G.tile_rows;
-    if (int rc = allow_lds(qp_prepare_kernel, G.lds_bytes)) return rc;
-    hipLaunchKernelGGL(qp_prepare_kernel, dim3((unsigned)B), dim3(G.threads), G.lds_bytes, (hipStream_t)stream, Q);
-    if (int rc = check_launch("qp_prepare_kernel")) return rc;
+    if (int rc = launch_prepare(G, Q, B, (hipStream_t)stream)) return rc;
     SolveParams P;
     memset(&P, 0, sizeof(P));
     P.ws = ws; P.ws_stride = (long long)L.total; P.ws_status = ws_status;

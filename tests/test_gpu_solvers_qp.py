@@ -3,6 +3,7 @@ test_programs.py:71-122), run through the drop-in API of the `hip` backend on th
 values are the data those tests hold; assertions mirror theirs."""
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -119,3 +120,40 @@ def test_qp_badly_scaled_rows_vs_oracle(oracle, n, m, B):
         assert np.allclose(sg['argmin'], so['argmin'], rtol=1e-6, atol=1e-6 * max(1, np.abs(so['argmin']).max())), k
         assert abs(sg['min'] - so['min']) <= 1e-6 * max(1., abs(so['min'])), k
     assert 0 < nfeas < B and nlimit <= B // 4
+
+
+@pytest.mark.parametrize("n,m", [(3, 40), (10, 250), (16, 70)])
+def test_wave_prepare_kernel_same_bits_as_tile_kernel(n, m, oracle):
+    """Batches of >= 1024 problems with up to 16 variables are factorised by qp_prepare_wave_kernel (one wavefront per
+    problem, constraint rows in registers) instead of qp_prepare_kernel (row tiles in LDS): launch policy
+    (pympc_hip_tune "prepare_wave").  Same sums in the same order: every output bitwise the same; and a sample of the
+    batch against the oracle's quadratic_program (pnnls.py:149-241)."""
+    from pympc_amd import _hip
+    from pympc_amd.optimization.solvers.hip import quadratic_program_batch
+    rng = np.random.RandomState(10 * n + m)
+    B = 1500
+    G = rng.randn(B, n, n)
+    H = np.einsum('bij,bkj->bik', G, G) + 0.5 * np.eye(n)[None]
+    f = rng.randn(B, n)
+    A = rng.randn(B, m, n)
+    b = 0.3 + rng.rand(B, m)
+    b[::7] -= 2.0                                   # some infeasible ones
+    outs = []
+    for wave in (1, 0):
+        with _hip.tuned(prepare_wave=wave):
+            r = quadratic_program_batch(H, f, A, b, want_iters=True)
+            outs.append({k: v.clone() for k, v in r.t.items() if v is not None})
+    for k in outs[0]:
+        a, c = outs[0][k], outs[1][k]
+        if a.dtype.is_floating_point:
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(c, nan=-7.0)), k
+        else:
+            assert torch.equal(a, c), k
+    st = outs[0]["status"].cpu().numpy()
+    assert (st == 0).sum() > 100 and (st == 1).sum() > 50
+    for i in range(0, B, 97):
+        ref = oracle.quadratic_program(H[i], f[i], A[i], b[i])
+        assert (ref['min'] is None) == (st[i] != 0), i
+        if ref['min'] is not None:
+            assert abs(outs[0]["min"][i].item() - ref['min']) < 1e-6 * max(1.0, abs(ref['min']))
+            assert np.allclose(outs[0]["argmin"][i].cpu().numpy(), ref['argmin'], rtol=1e-6, atol=1e-6)

@@ -48,7 +48,7 @@ const char *pympc_hip_last_error(void);
  * between kernels that implement the SAME method -- never what is computed -- so that every kernel can be driven at every
  * size.  `value` < 0 only queries; `previous` (may be NULL) receives the value before the call.  Keys:
  *   "lp_tile_min_rows" / "lp_tile_min_batch"   pympc_lp_solve_batch runs the eight-LPs-per-workgroup kernel from this many
- *                                              rows / LPs against one shared matrix (defaults 2048 / 1024)
+ *                                              rows / LPs against one shared matrix (defaults 1024 / 1024)
  *   "gram_min_batch"     pympc_mpqp_solve_batch* runs the Gram-form kernel from this many states (default 8192).  NOTE:
  *                        states with 3..8 active constraints are then finished by a different kernel than in a smaller
  *                        batch: same method and decisions, values equal to rounding (1e-9), so argmin / min / multipliers

@@ -23,7 +23,7 @@
 namespace pympc {
 
 constexpr int kLpTileWaves = 8;
-constexpr int kLpTileMinRows = 2048;    // below this lp_block.hpp (one small workgroup per LP) fills the chip better
+constexpr int kLpTileMinRows = 1024;    // below this lp_block.hpp (one small workgroup per LP) fills the chip better (8 442 LPs x 1 558 rows: 1.51 against 1.83 ms)
 constexpr int kLpTileMinBatch = 1024;
 constexpr int kLpTileCtl = 160;   // doubles ahead of the per-wave blocks: 128 control ints, 64 arg-max values, 64 indices
 

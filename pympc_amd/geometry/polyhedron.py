@@ -213,21 +213,25 @@ class Polyhedron(object):
                 raise RuntimeError('Maximum number of iterations reached.')
             return np.where(st == 0, -mn - f[idx], np.inf)
 
-        # 1. all facets against the full relaxed set
-        res = hip_lp.linear_program_batch(-E, E, f, relax_idx=np.arange(m, dtype=np.int32), relax_val=1.,
-                                          want_argmin=False, want_mult=False, want_active=False)
-        v1 = values(res, np.arange(m))
-        cand = np.where(v1 < tol)[0]
-        sure = np.where(~(v1 < tol))[0]
         removed = np.zeros(m, bool)
-        undecided = cand
-        # 2. candidates against the surely kept facets
-        if cand.size > 0 and sure.size > 0:
-            res = hip_lp.linear_program_batch(-E[cand], E[sure], f[sure], want_argmin=False, want_mult=False,
-                                              want_active=False)
-            v2 = values(res, cand)
-            gone = v2 < tol
-            undecided = cand[~gone]
+        staged = self._minimal_facets_staged(E, f, tol, values) if m >= self.STAGED_MIN_FACETS else None
+        if staged is not None:
+            cand, sure, undecided = staged
+        else:
+            # 1. all facets against the full relaxed set
+            res = hip_lp.linear_program_batch(-E, E, f, relax_idx=np.arange(m, dtype=np.int32), relax_val=1.,
+                                              want_argmin=False, want_mult=False, want_active=False)
+            v1 = values(res, np.arange(m))
+            cand = np.where(v1 < tol)[0]
+            sure = np.where(~(v1 < tol))[0]
+            undecided = cand
+            # 2. candidates against the surely kept facets
+            if cand.size > 0 and sure.size > 0:
+                res = hip_lp.linear_program_batch(-E[cand], E[sure], f[sure], want_argmin=False, want_mult=False,
+                                                  want_active=False)
+                v2 = values(res, cand)
+                gone = v2 < tol
+                undecided = cand[~gone]
         # 3. the rest in index order, against the reference's current set
         pending_sure = set(cand.tolist()) - set(undecided.tolist())   # removed when their turn comes
         for i in undecided:
@@ -240,6 +244,65 @@ class Polyhedron(object):
                 removed[i] = True
         removed[list(pending_sure)] = True
         return [int(i) for i in np.where(~removed)[0]]
+
+    STAGED_MIN_FACETS = 2000
+
+    @staticmethod
+    def _minimal_facets_staged(E, f, tol, values):
+        """
+        Steps 1 and 2 of minimal_facets for many facets, with the same outcome (cand, sure, undecided) at a fraction of the
+        row sweeps.  Step 1 solves one LP per facet against ALL m rows although most facets are redundant against a
+        small subset already:
+          a. Z = the facets hit first by rays from an interior point along every facet normal (one matrix product; a
+             guess only, nothing below relies on it);
+          b. every facet outside Z against the rows of Z alone (no relaxation: its own row is not among them): redundant
+             there (value < tol) means redundant against any superset, hence value < tol against the full relaxed set
+             too: a candidate of step 1 -- and, if Z turns out to lie in `sure`, "gone" in step 2;
+          c. only Z and the facets that b. did not settle get step 1's LP against the full relaxed set.
+        If some member of Z is not surely kept (duplicated or touching facets: its own full test says so), b. proves
+        nothing about step 2 and None is returned: the caller runs the plain steps.
+        """
+        import torch
+        from .. import _hip
+        m, n = E.shape
+        if np.min(f) <= 1.e-9:            # (the origin must be strictly inside; callers with other data take the plain path)
+            return None
+        dev = _hip.device()
+        E64 = _hip.to_device(E); f64 = _hip.to_device(f)               # (the LP batches below index these on the device)
+        # (single precision: the rays only propose a subset)
+        Ed = E64.to(torch.float32); fd = f64.to(torch.float32)
+        Dn = (Ed / torch.linalg.norm(Ed, dim=1, keepdim=True)).T.contiguous()        # [n x m] ray directions
+        hit = torch.empty(m, dtype=torch.int64, device=dev)
+        for c0 in range(0, m, 4096):                                   # rays x = t a_i / |a_i|: first facet k with a_k x = f_k
+            S = Ed.mm(Dn[:, c0:c0 + 4096])                             # a_k . d_i
+            S.clamp_(min=1.e-12).reciprocal_().mul_(fd[:, None])       # t = f_k / (a_k . d_i); rays that never meet row k: huge
+            hit[c0:c0 + 4096] = S.argmin(dim=0)
+        inZ = torch.zeros(m, dtype=torch.bool, device=dev); inZ[hit] = True
+        Zt = torch.nonzero(inZ).reshape(-1)
+        rest_t = torch.nonzero(~inZ).reshape(-1)
+        Z = Zt.cpu().numpy()
+        if Z.size < n + 1 or Z.size > m // 2:
+            return None
+        rest = rest_t.cpu().numpy()
+        res = hip_lp.linear_program_batch(-E64[rest_t], E64[Zt], f64[Zt], want_argmin=False, want_mult=False, want_active=False)
+        settled = values(res, rest) < tol                              # redundant against Z alone
+        full = np.concatenate((Z, rest[~settled]))
+        full.sort()
+        full_t = torch.as_tensor(full, device=dev)
+        res = hip_lp.linear_program_batch(-E64[full_t], E64, f64, relax_idx=full_t.to(torch.int32), relax_val=1.,
+                                          want_argmin=False, want_mult=False, want_active=False)
+        v1 = values(res, full)
+        sure = full[~(v1 < tol)]
+        if not np.all(np.isin(Z, sure)):
+            return None
+        cand_full = full[v1 < tol]
+        cand = np.sort(np.concatenate((rest[settled], cand_full)))
+        undecided = cand_full
+        if cand_full.size > 0 and sure.size > 0:                       # step 2 for the candidates b. did not settle
+            res = hip_lp.linear_program_batch(-E[cand_full], E[sure], f[sure], want_argmin=False, want_mult=False,
+                                              want_active=False)
+            undecided = cand_full[~(values(res, cand_full) < tol)]
+        return cand, sure, undecided
 
     def remove_redundant_inequalities(self):
         """Removes the redundant facets of the polyhedron, it modifies the attributes A and b (polyhedron.py:452-466)."""

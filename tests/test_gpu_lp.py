@@ -83,7 +83,7 @@ def test_polytope_vs_reference_golden(m):
 
 @pytest.mark.parametrize("m", [30, 60, 100])
 def test_lockstep_kernel_on_reference_polytopes(m):
-    """lp_tile_kernel (eight LPs per workgroup in lockstep: the kernel config C3 is timed on) normally starts at 2048
+    """lp_tile_kernel (eight LPs per workgroup in lockstep: the kernel config C3 is timed on) normally starts at 1024
     rows / 1024 LPs, sizes the reference cannot run.  With the launch thresholds lowered (pympc_hip_tune) it runs the
     reference-run golden polytopes:
       * the reference's own sequence of LPs (polyhedron.py:435-448: facet i against the set with the earlier redundant
@@ -111,7 +111,7 @@ def test_lockstep_kernel_on_reference_polytopes(m):
             got[i] = -r.numpy('min')[0] - b[i]
             if vals[i] < 1e-7:            # the reference dropped facet i here (polyhedron.py:447-448)
                 keep.remove(i)
-    assert _hip.tune("lp_tile_min_rows") == 2048 and _hip.tune("lp_tile_min_batch") == 1024
+    assert _hip.tune("lp_tile_min_rows") == 1024 and _hip.tune("lp_tile_min_batch") == 1024
     assert keep == list(g["m%d_minimal_facets" % m])
     assert np.allclose(got, vals, rtol=1e-6, atol=1e-6)
     assert mf == list(g["m%d_minimal_facets" % m])                            # bit-exact index list (reference run)

@@ -196,3 +196,29 @@ def test_errors_where_the_reference_fails():
     assert box.is_included_in(Polyhedron.from_bounds(-2. * np.ones(2), 2. * np.ones(2)))
     with pytest.raises(TypeError):
         half.is_included_in(box)
+
+
+@pytest.mark.parametrize("m,dup", [(3000, 0), (2500, 40)])
+def test_staged_redundancy_removal_same_list(m, dup):
+    """Polytopes with >= 2000 facets take minimal_facets' staged first steps (ray-shot subset, every other facet against
+    that subset, the full-set LP only for what is left): the index list must be the plain path's, also with duplicated and
+    scaled-duplicate facets (which the reference's sequential rule, polyhedron.py:435-448, resolves by index order)."""
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    rng = np.random.RandomState(m)
+    A = rng.randn(m, 4); A /= np.linalg.norm(A, axis=1)[:, None]
+    b = 1. + rng.rand(m)
+    if dup:
+        src = rng.choice(m, dup, replace=False)
+        dst = rng.choice(m, dup, replace=False)
+        scale = 1. + rng.rand(dup)
+        A[dst] = A[src] * scale[:, None]; b[dst] = b[src] * scale
+    staged = Polyhedron(A.copy(), b.copy()).minimal_facets()
+    plain_poly = Polyhedron(A.copy(), b.copy())
+    plain_poly.STAGED_MIN_FACETS = 10 ** 9
+    plain = plain_poly.minimal_facets()
+    assert staged == plain
+    assert 30 < len(staged) < m // 2
+    # every kept facet is tight somewhere on the polytope, every removed one is implied: vertices of the kept set satisfy all rows
+    P = Polyhedron(A[staged], b[staged])
+    V = np.array(P.vertices)
+    assert (A.dot(V.T) - b[:, None]).max() < 1e-6

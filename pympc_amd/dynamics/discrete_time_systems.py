@@ -198,6 +198,13 @@ def mcais(A, X, verbose=False):
     Maximal constraint-admissible invariant set of x(t+1) = A x(t), x in X (Gilbert-Tan Algorithm 3.2,
     discrete_time_systems.py:584-674).  The reference solves one LP per facet of X at every iteration
     (:646-648); all of them share the constraint set O_inf, so each iteration is ONE batched launch.
+
+    Several iterations per launch: the rows X.A A^t, ..., X.A A^(t+k-1) are all tested against the set as it stands before
+    iteration t.  That set has fewer rows than the ones the later iterations would see, so a row found redundant is
+    redundant for the reference too, and a row found necessary is at worst a redundant extra that the final
+    remove_redundant_inequalities takes out again; the first iteration of the block without a new row ends the
+    algorithm as it does in the reference (whose own stop can only come earlier, after which every further row is
+    redundant by invariance).  Same minimal set, a launch and a host round trip per k iterations instead of per iteration.
     """
     from ..optimization.solvers import hip_lp
     if np.max(np.absolute(np.linalg.eigvals(A))) > 1.:
@@ -210,23 +217,33 @@ def mcais(A, X, verbose=False):
     O_inf = copy(X)
     At = np.eye(nx)
     t = 1
-    while True:
-        At = At.dot(A)
-        J = X.A.dot(At)
-        res = hip_lp.linear_program_batch(-J, O_inf.A, O_inf.b, want_argmin=False, want_mult=False, want_active=False)
+    mX = X.A.shape[0]
+    block = 2
+    done = False
+    while not done:
+        Js = []
+        for _ in range(block):
+            At = At.dot(A)
+            Js.append(X.A.dot(At))
+        res = hip_lp.linear_program_batch(-np.vstack(Js), O_inf.A, O_inf.b, want_argmin=False, want_mult=False,
+                                          want_active=False)
         st = res.numpy('status')
         if np.any(st == 3):
             raise RuntimeError('Maximum number of iterations reached.')
         if np.any(st != 0):
             raise TypeError('an LP of the invariant-set iteration has no optimum (the reference fails on -None here).')
-        residuals = -res.numpy('min') - X.b
-        if verbose:
-            print('Time horizon: %d. Convergence index: %g. Number of facets: %d.' % (t, residuals.max(), O_inf.A.shape[0]))
-        new_facets = np.where(residuals > 0.)[0]
-        if new_facets.size == 0:
-            break
-        O_inf.add_inequality(J[new_facets], X.b[new_facets])
-        t += 1
+        vals = -res.numpy('min')
+        for s, J in enumerate(Js):
+            residuals = vals[s * mX:(s + 1) * mX] - X.b
+            if verbose:
+                print('Time horizon: %d. Convergence index: %g. Number of facets: %d.' % (t, residuals.max(), O_inf.A.shape[0]))
+            new_facets = np.where(residuals > 0.)[0]
+            if new_facets.size == 0:
+                done = True
+                break
+            O_inf.add_inequality(J[new_facets], X.b[new_facets])
+            t += 1
+        block = min(2 * block, 16)
     O_inf.remove_redundant_inequalities()
     if verbose:
         print('minimal facets are ' + str(O_inf.A.shape[0]) + '.')

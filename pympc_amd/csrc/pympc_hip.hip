@@ -251,7 +251,7 @@ int solve_common(bool shared, int n, int m, int p, SolveParams &P, hipStream_t s
                     shared_bytes, wave_bytes);
     int nwaves = (int)((kLdsBytes - shared_bytes - kSolveCtlBytes) / wave_bytes);
     // without a staged matrix keep workgroups small so several fit a CU and balance at wave granularity
-    const int max_waves = mt <= 8 ? 12 : 4;   // = solve_max_waves<MT>() (launch bounds of the kernel)
+    const int max_waves = mt <= 8 ? PYMPC_SOLVE_WAVES : 4;   // = solve_max_waves<MT, true>() (launch bounds of the kernel)
     const int cap = shared ? max_waves : 4;
     if (nwaves > cap) nwaves = cap;
     if (shared && nwaves > 4) nwaves &= ~3;   // a multiple of the 4 SIMDs

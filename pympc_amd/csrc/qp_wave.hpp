@@ -732,13 +732,20 @@ __device__ __forceinline__ long long sched_next(const SolveParams &P, int *ctl, 
 
 // Workgroup = NW waves; it owns problems [blockIdx.x * chunk, ...) and hands them to its waves through an LDS
 // ticket.  SHARED: the constant rows Mt / m0 / Gm and the objective tables are staged in LDS once per workgroup.
-// waves per workgroup: 12 (3 per SIMD, 168 VGPRs) up to 8 columns per lane, 4 (512 VGPRs) beyond, so that
-// the per-lane column arrays mv / w / acc / row never spill to scratch
-template <int MT>
-constexpr int solve_max_waves() { return MT <= 8 ? 12 : 4; }
+// waves per workgroup: 8 (2 per SIMD, 213 VGPRs at MT = 6, nothing spilled) up to 8 columns per lane, 4 (512 VGPRs)
+// beyond.  Until round 3: 12 (168 VGPRs, 51 of them spilled: 32 MB of scratch written per 1 M-state step).  Since the
+// Gram-form kernel hands its states over with their columns, this kernel's time is the longest single chain of pivots,
+// not the number of waves: 8 measured 1 % (s = 0.3) and 4 % (s = 1.0) faster per step than 12
+#ifndef PYMPC_SOLVE_WAVES
+#define PYMPC_SOLVE_WAVES 8
+#endif
+// (per-problem matrices, SHARED = false: workgroups of 4 waves, many problems of equal length: there the number of
+// resident waves is what counts, so the register budget stays that of 3 waves per SIMD)
+template <int MT, bool SHARED>
+constexpr int solve_max_waves() { return MT <= 8 ? (SHARED ? PYMPC_SOLVE_WAVES : 12) : 4; }
 
 template <int MT, bool SHARED>
-__global__ void __launch_bounds__(64 * solve_max_waves<MT>()) qp_solve_kernel(SolveParams P)
+__global__ void __launch_bounds__((64 * solve_max_waves<MT, SHARED>())) qp_solve_kernel(SolveParams P)
 {
     extern __shared__ double lds[];
     constexpr int mp = 64 * MT;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load_library()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.pympc_hip_abi_version() >= 6   # 6: raw NNLS / PNNLS and the static-scratch mpQP entry points
+    assert lib.pympc_hip_abi_version() >= 8   # 8: pympc_point_location with decided cells and decision lists
     nmax, mmax = _hip.limits()
     assert nmax >= 20 and mmax >= 370
     assert lib.pympc_mpqp_workspace_doubles(20, 370, 4) > 20 * 370 + 384 * 384   # 370 rows padded to 384 columns

@@ -182,7 +182,7 @@ def c4():
     G, geom = tab['grid']['n'], torch.as_tensor(tab['grid']['geom'], device='cuda')
     cell = ((X - geom[:2]) * geom[2:4]).floor().clamp_(0, G - 1).long()
     dec = tab['grid']['sure'][cell[:, 0] * G + cell[:, 1]] != -2
-    dec |= ((X < geom[:2]) | (X > geom[4:])).any(dim=1)
+    dec |= ((X < geom[6:8]) | (X > geom[4:6])).any(dim=1)
     wave_dec = torch.nn.functional.pad(dec, (0, (-B) % 64), value=True).reshape(-1, 64).all(dim=1)
     sample = X[::50].cpu().numpy()
     t0 = time.perf_counter(); O.point_location({k: tab[k] for k in ('A', 'b', 'row_ptr', 'ux', 'u0', 'Vxx', 'Vx', 'V0')}, sample)

@@ -273,15 +273,17 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
  * box [nreg x 2 p] (p lower bounds, then p upper bounds; may be NULL): per region an axis-aligned box that contains
  * every point its row test can accept; regions whose box holds none of a wavefront's points are skipped.  It only
  * prunes: the result is the reference's first-hit region whatever the boxes are, as long as they are not too small.
- * Cell grid (may be NULL / 0): grid_geom [3 p] = lower corner of a uniform grid of grid_n cells per axis, then
- * 1 / cell size per axis, then the upper corner; grid_masks [grid_n^p x ceil(nreg/64)] uint64, cell index = ((c_0 grid_n + c_1) grid_n + ...),
+ * Cell grid (may be NULL / 0): grid_geom [4 p] = lower corner of a uniform grid of grid_n cells per axis, then
+ * 1 / cell size per axis, then the upper and the lower corner of the box outside which a point lies in no region (used
+ * with grid_sure only; +-inf switches that shortcut off); grid_masks [grid_n^p x ceil(nreg/64)] uint64, cell index = ((c_0 grid_n + c_1) grid_n + ...),
  * bit r % 64 of word r / 64 set iff region r can contain a point of the cell (points outside the grid are looked up
  * in the nearest cell).  Like the boxes it only prunes: a missing bit is only allowed for a region that contains no
  * point of the cell.
  * grid_sure [grid_n^p] int32 (may be NULL; needs the grid): r >= 0 = every point of the cell passes the row test of
  * region r for any tol >= 0 and no earlier region can contain a point of the cell; -1 = no region can; -2 = undecided
- * (the cell's bit set is scanned).  Points outside [lower corner, upper corner] are taken to lie in no region, so the
- * grid must cover every region.  Unlike the boxes and bit sets this one DECIDES: a wrong entry is a wrong result.
+ * (the cell's bit set is scanned).  Points outside the box of grid_geom are taken to lie in no region; the others are
+ * looked up in the nearest cell, so with an unbounded box the border cells must be -2.  Unlike the boxes and bit sets
+ * this one DECIDES: a wrong entry is a wrong result.
  * grid_lists (int32 pool, may be NULL): grid_sure <= -3 means -3 - grid_sure is the offset of the cell's decision list
  * [ncand, (region, nrows, row_0 .. row_{nrows-1}) x ncand]: the candidate regions of the cell in ascending order, each
  * with the rows (indices into A / b) that do not hold on the whole cell; a point of the cell lies in the first

@@ -43,7 +43,8 @@ struct PlParams {
     const int32_t *row_ptr;
     const double *ux, *u0, *Vxx, *Vx, *V0;
     const double *box;   // [nreg x 2 p] (lower bounds, then upper bounds) or null
-    const double *grid_geom;              // [3 p]: lower corner of the cell grid, 1 / cell size per axis, upper corner; or null
+    const double *grid_geom;              // [4 p]: lower corner of the cell grid, 1 / cell size per axis, then the box outside
+                                          //   which a point lies in no region: its upper and its lower corner; or null
     const unsigned long long *grid_masks; // [grid_n^p x ceil(nreg / 64)]: bit r of a cell = region r can touch the cell
     const int32_t *grid_sure;             // [grid_n^p]: decided cells (see above) or null
     const int32_t *grid_lists;            // decision lists of the cells with grid_sure <= -3 (pool of int32) or null
@@ -327,9 +328,9 @@ __global__ void __launch_bounds__(256) point_cells_kernel(PlParams P)
     const long long stride = (long long)gridDim.x * (blockDim.x >> 6) * chunk;
     const long long base0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * chunk;
     const cdouble_ptr geom = as_const(P.grid_geom);
-    double g0[PD], gi[PD], g1[PD];
+    double g0[PD], gi[PD], g1[PD], gl[PD];
 #pragma unroll
-    for (int q = 0; q < PD; ++q) { g0[q] = geom[q]; gi[q] = geom[PD + q]; g1[q] = geom[2 * PD + q]; }
+    for (int q = 0; q < PD; ++q) { g0[q] = geom[q]; gi[q] = geom[PD + q]; g1[q] = geom[2 * PD + q]; gl[q] = geom[3 * PD + q]; }
     const double gmax = (double)(P.grid_n - 1);
     for (long long base = base0; base < P.B; base += stride) {
         double x[U][PD];
@@ -343,12 +344,13 @@ __global__ void __launch_bounds__(256) point_cells_kernel(PlParams P)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             // a point with a NaN coordinate lies in no region (contains: max(A x - b) <= tol is False, polyhedron.py:596);
-            // outside the grid = outside the hull of the region boxes: in no region either (both comparisons fail on NaN)
+            // outside the box the host gives (the hull of the region boxes, when all are bounded) in no region either (both
+            // comparisons fail on NaN)
             bool in = true;
             int cell = 0;
 #pragma unroll
             for (int q = 0; q < PD; ++q) {
-                in = in && (x[u][q] >= g0[q]) && (x[u][q] <= g1[q]);
+                in = in && (x[u][q] >= gl[q]) && (x[u][q] <= g1[q]);
                 const double c = fmin(fmax(floor((x[u][q] - g0[q]) * gi[q]), 0.0), gmax);
                 cell = cell * P.grid_n + (int)c;
             }

@@ -155,7 +155,7 @@ def test_point_location_vs_oracle(nb, oracle):
     # decided cells: most of the grid, and each one is right at its centre and corners (first hit of the plain scan)
     sure = grid['sure'].cpu().numpy()
     assert (sure > -2).mean() > .5 and (sure >= 0).any() and (sure == -1).any()
-    lo, inv, hi = grid['geom'][:2], grid['geom'][2:4], grid['geom'][4:]
+    lo, inv, hi = grid['geom'][:2], grid['geom'][2:4], grid['geom'][4:6]
     cc = np.stack(np.meshgrid(np.arange(G), np.arange(G), indexing='ij'), axis=-1).reshape(-1, 2)
     for off in ((.5, .5), (1e-6, 1e-6), (1 - 1e-6, 1e-6), (1e-6, 1 - 1e-6), (1 - 1e-6, 1 - 1e-6)):
         Xc = lo + (cc + np.array(off)) / inv
@@ -315,6 +315,15 @@ def test_point_location_higher_dimensional_tables_vs_oracle(oracle, p):
     # identical with every pruning device switched off (plain list scan)
     c = es.locate(X, nu=2, use_boxes=False, use_grid=False)
     assert np.array_equal(c[0].cpu().numpy(), idx)
+    # ... and with the per-cell pass forced on and off (launch policy: it runs when most cells are decided or listed);
+    # the p = 4 table has regions without a finite box: border cells stay with the scan, no point counts as outside
+    grid = es.table(2)['grid']
+    assert grid is not None
+    for force in (True, False):
+        grid['use_sure'] = force
+        d = es.locate(X, nu=2)
+        assert np.array_equal(d[0].cpu().numpy(), idx)
+        assert np.array_equal(d[1].cpu().numpy(), u, equal_nan=True) and np.array_equal(d[2].cpu().numpy(), V, equal_nan=True)
 
 
 def test_nan_points_and_empty_table(nb, oracle):

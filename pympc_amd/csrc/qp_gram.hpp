@@ -29,6 +29,9 @@
 
 namespace pympc {
 
+#ifndef PYMPC_GRAM_LEAN
+#define PYMPC_GRAM_LEAN 1
+#endif
 constexpr int kGramThreads = 768;       // one workgroup per CU: 12 waves (3 per SIMD, 168 VGPRs: nothing spills) draw from one pool of slices
 constexpr int kGramSlice = 16;           // states per ticket of a wave (<= 64)
 constexpr int kGramK = 8;               // passive columns up to which a state stays in this kernel (<= 8: wsum8)
@@ -201,9 +204,13 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
                         w[2 * h + 1] = fma(yv[u], a[u][h].y, w[2 * h + 1]);
                     }
             }
+#if !PYMPC_GRAM_LEAN
 #pragma unroll
             for (int s = 0; s < MT; ++s)
                 if (col_of(lane, s) >= m || ((inP >> s) & 1u)) w[s] = -1.0;
+#endif
+            // (lean: no masking needed.  A pad column has m = 1 and a zero Gram row: w = -gam < 0.  A passive column meets
+            // its own diagonal entry, stored as kGramDiag = 1e300: w = -y 1e300, hugely negative for its positive y.)
         }
         PYMPC_TICK(5)
         // ---------------- the column of largest guaranteed decrease (the rule of qp_wave_solve), tested in Gram form
@@ -220,11 +227,25 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
                     sc[2 * h] = v.x;
                     sc[2 * h + 1] = v.y;
                 }
+            }
+#if PYMPC_GRAM_LEAN
+            // score and column in one key, straight-line as in the lane path (qp_screen.hpp): w^2 / (cn + m^2) is compared
+            // through s = w rsq(cn + m^2) (same order for w > 0, negative otherwise), the low 10 mantissa bits give way to
+            // 1023 - column: ONE max per column and one max-reduction return the best column (lowest index among scores
+            // equal to 2^-42 relative); a negative key never beats the initial 0
+            double best = 0.0;
 #pragma unroll
-                for (int s = 0; s < MT; ++s) {
-                    const double d = fma(mv[s], mv[s], sc[s]);
-                    sc[s] = (w[s] > 0.0) ? w[s] * w[s] * __builtin_amdgcn_rcp(d) : -1.0;
-                }
+            for (int s = 0; s < MT; ++s) {
+                const double d = fma(mv[s], mv[s], sc[s]);
+                const double sv = w[s] * __builtin_amdgcn_rsq(d);
+                const long long key = (__double_as_longlong(sv) & ~0x3ffLL) | (long long)(1023 - col_of(lane, s));
+                best = max_raw(best, __longlong_as_double(key));
+            }
+#else
+#pragma unroll
+            for (int s = 0; s < MT; ++s) {
+                const double d = fma(mv[s], mv[s], sc[s]);
+                sc[s] = (w[s] > 0.0) ? w[s] * w[s] * __builtin_amdgcn_rcp(d) : -1.0;
             }
             // score and column in one key: the low 10 mantissa bits of the (positive) score give way to 1023 - column, so
             // that ONE max-reduction returns the best column (lowest index among scores equal to 2^-42 relative)
@@ -235,8 +256,10 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
                 const double kd = (sc[s] > 0.0) ? __longlong_as_double(key) : -1.0;
                 best = max_raw(best, kd);
             }
+#endif
             const double gmax = wmax(best);
-            if (!(gmax > 0.0)) {   // no column enters: optimal on the current passive set
+            // (lean keys: a column with w = 0 exactly packs to a denormal, not to zero: everything below 1e-290 is "no gain")
+            if (!(gmax > (PYMPC_GRAM_LEAN ? 1e-290 : 0.0))) {   // no column enters: optimal on the current passive set
                 if (stale) (void)gram_solve();   // ... whose solution the refused trials overwrote
                 break;
             }
@@ -288,7 +311,7 @@ __device__ __forceinline__ void gram_wave_solve(const SolveParams &P, long long 
             if (lane == jl) {
 #pragma unroll
                 for (int s = 0; s < MT; ++s)
-                    if (s == js) w[s] = 0.0;
+                    if (s == js) w[s] = -1.0;   // (refused: out of this round's arg-max)
             }
         }
         if (giveup || !accepted) break;

@@ -473,6 +473,39 @@ class ExplicitSolution(object):
                     decided_fraction=decided, listed_fraction=listed, use_sure=(decided + listed) >= cls.SURE_MIN_FRACTION,
                     needs_scan=bool((sure == -2).any().item()))
 
+    @staticmethod
+    def _assemble_lists(cand_u, cand_r, cand_k, row_i, ncell, cap):
+        """
+        The int32 pool of the cells' decision lists from the candidates sorted by (cell, region): cand_u / cand_r / cand_k
+        = cell, region and number of crossing rows of every candidate, row_i = the rows of all candidates in that order.
+        A cell's list ends at its first candidate without a crossing row; lists longer than `cap` ints are dropped (code -2).
+        Returns (pool with a dummy entry 0, codes [ncell]: -3 - offset of the cell's list).  numpy only (tests/test_abi.py).
+        """
+        ncand = cand_u.size
+        cstart = np.searchsorted(cand_u, np.arange(ncell + 1))
+        rstart = np.concatenate(([0], np.cumsum(cand_k)))            # rows of candidate j: row_i[rstart[j]:rstart[j + 1]]
+        zero = (cand_k == 0).astype(np.int64)
+        cz = np.cumsum(zero) - zero                                   # candidates without rows before j (all cells)
+        first = np.minimum(cstart[:-1], max(ncand - 1, 0))
+        keep = (cz - cz[first][cand_u]) == 0
+        ints = np.where(keep, 2 + cand_k, 0)
+        ci = np.cumsum(ints) - ints
+        nonempty = cstart[1:] > cstart[:-1]
+        cell_ints = 1 + np.add.reduceat(np.concatenate((ints, [0])), cstart[:-1]) * nonempty
+        cell_ok = (cell_ints <= cap) & nonempty
+        used = np.where(cell_ok, cell_ints, 0)
+        cell_off = 1 + np.cumsum(used) - used                         # pool[0] is a dummy
+        pool = np.zeros(1 + int(used.sum()), np.int32)
+        kc = keep & cell_ok[cand_u]
+        pos = cell_off[cand_u] + 1 + (ci - ci[first][cand_u])
+        pool[cell_off[cell_ok]] = np.add.reduceat(np.concatenate((keep.astype(np.int64), [0])), cstart[:-1])[cell_ok]
+        pool[pos[kc]] = cand_r[kc]
+        pool[pos[kc] + 1] = cand_k[kc]
+        rcand = np.repeat(np.arange(ncand), cand_k)                   # candidate of every row entry (same order as row_i)
+        rk = kc[rcand]
+        pool[(pos[rcand] + 2 + (np.arange(rcand.size) - rstart[rcand]))[rk]] = row_i[rk]
+        return pool, np.where(cell_ok, -3 - cell_off, -2).astype(np.int64)
+
     LIST_MAX_INTS = 48        # longest decision list of a cell (beyond it the cell is left to the scan)
 
     @classmethod
@@ -527,29 +560,7 @@ class ExplicitSolution(object):
         row_u = torch.cat(row_u).cpu().numpy(); row_r = torch.cat(row_r).cpu().numpy(); row_i = torch.cat(row_i).cpu().numpy()
         o = np.lexsort((cand_r, cand_u)); cand_u, cand_r, cand_k = cand_u[o], cand_r[o], cand_k[o]
         o = np.lexsort((row_i, row_r, row_u)); row_u, row_i = row_u[o], row_i[o]
-        nund = und.numel()
-        ncand = cand_u.size
-        cstart = np.searchsorted(cand_u, np.arange(nund + 1))
-        rstart = np.concatenate(([0], np.cumsum(cand_k)))            # rows of candidate j: row_i[rstart[j]:rstart[j + 1]]
-        # a cell's list ends at its first candidate without a crossing row
-        zero = (cand_k == 0).astype(np.int64)
-        cz = np.cumsum(zero) - zero                                   # candidates without rows before j (all cells)
-        keep = (cz - cz[np.minimum(cstart[:-1], ncand - 1)][cand_u]) == 0
-        ints = np.where(keep, 2 + cand_k, 0)
-        ci = np.cumsum(ints) - ints
-        cell_ints = 1 + np.add.reduceat(np.concatenate((ints, [0])), cstart[:-1]) * (cstart[1:] > cstart[:-1])
-        cell_ok = (cell_ints <= cls.LIST_MAX_INTS) & (cstart[1:] > cstart[:-1])
-        cell_off = 1 + np.cumsum(np.where(cell_ok, cell_ints, 0)) - np.where(cell_ok, cell_ints, 0)    # pool[0] is a dummy
-        pool = np.zeros(1 + int(np.where(cell_ok, cell_ints, 0).sum()), np.int32)
-        kc = keep & cell_ok[cand_u]
-        pos = cell_off[cand_u] + 1 + (ci - ci[np.minimum(cstart[:-1], ncand - 1)][cand_u])
-        pool[cell_off[cell_ok]] = np.add.reduceat(np.concatenate((keep.astype(np.int64), [0])), cstart[:-1])[cell_ok]
-        pool[pos[kc]] = cand_r[kc]
-        pool[pos[kc] + 1] = cand_k[kc]
-        rcand = np.repeat(np.arange(ncand), cand_k)                   # candidate of every row entry (same order as row_i)
-        rk = kc[rcand]
-        pool[(pos[rcand] + 2 + (np.arange(rcand.size) - rstart[rcand]))[rk]] = row_i[rk]
-        codes = np.where(cell_ok, -3 - cell_off, -2).astype(np.int64)
+        pool, codes = cls._assemble_lists(cand_u, cand_r, cand_k, row_i, und.numel(), cls.LIST_MAX_INTS)
         sure = sure.clone()
         sure[und] = torch.as_tensor(codes, device=dev).to(torch.int32)
         return torch.as_tensor(pool, device=dev), sure, float((codes <= -3).sum()) / sure.numel()

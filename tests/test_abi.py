@@ -3,6 +3,7 @@ compute call is made (no GPU here)."""
 import os
 import re
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -56,3 +57,39 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("# the cpu oracle", ""), os.path.join(dirpath, f)
+
+
+def test_decision_list_assembly_matches_a_plain_loop():
+    """Host logic of the point-location table (ExplicitSolution._assemble_lists, numpy only): the vectorised assembly of the
+    per-cell decision lists against a straightforward loop, on random candidates -- truncation at the first candidate
+    without a crossing row, the length cap, offsets and codes."""
+    from pympc_amd.optimization.parametric_programs import ExplicitSolution
+    rng = np.random.RandomState(0)
+    cap = 48
+    ncell = 400
+    cu, cr, ck, ri = [], [], [], []
+    for u in range(ncell):
+        if u % 17 == 5:
+            continue                                      # a cell without candidates
+        for r in np.sort(rng.choice(50, rng.randint(1, 7), replace=False)):
+            k = rng.randint(0, 12) if rng.rand() < .8 else 0
+            cu.append(u); cr.append(int(r)); ck.append(k)
+            ri += list(np.sort(rng.choice(1000, k, replace=False)))
+    cu, cr, ck, ri = (np.array(v, dtype=np.int64) for v in (cu, cr, ck, ri))
+    pool, codes = ExplicitSolution._assemble_lists(cu, cr, ck, ri, ncell, cap)
+    start = np.searchsorted(cu, np.arange(ncell + 1))
+    rstart = np.concatenate(([0], np.cumsum(ck)))
+    ref_pool, ref_codes = [0], np.full(ncell, -2, np.int64)
+    for u in range(ncell):
+        ints = [0]
+        for j in range(start[u], start[u + 1]):
+            ints += [int(cr[j]), int(ck[j])] + ri[rstart[j]:rstart[j + 1]].tolist()
+            ints[0] += 1
+            if ck[j] == 0:
+                break
+        if start[u + 1] > start[u] and len(ints) <= cap:
+            ref_codes[u] = -3 - len(ref_pool)
+            ref_pool += ints
+    assert np.array_equal(pool, np.array(ref_pool, dtype=np.int32))
+    assert np.array_equal(codes, ref_codes)
+    assert (codes == -2).sum() > 10 and (codes <= -3).sum() > 200

@@ -79,6 +79,17 @@ def linear_program(f, A, b, C=None, d=None, tol=TOL):
     else:
         AC, bd = A, b
     res = linear_program_batch(f[None, :], AC, bd, tol=tol, n_eq=n_eq)
+    if int(res.t['status'][0].item()) == _hip.MAXITER:
+        # The active-set kernel can stall on a dual-degenerate LP (an objective that does not see most variables: the
+        # Chebyshev LP, max x_i over a polytope in (x, u)): thousands of pivots through ties, or its iteration limit.
+        # One more try with the objective tilted by 1e-9 (fixed seed), which breaks the ties; the value is reported for
+        # the objective asked for.  An LP that fails again raises as before.
+        ft = f + 1.e-9 * max(1., float(np.abs(f).max())) * np.random.RandomState(0).randn(f.size)
+        again = linear_program_batch(ft[None, :], AC, bd, tol=tol, n_eq=n_eq)
+        if int(again.t['status'][0].item()) == _hip.OPTIMAL:
+            sol = again.sol(0)
+            sol['min'] = float(f.dot(sol['argmin']))
+            return sol
     return res.sol(0)
 
 

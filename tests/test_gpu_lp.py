@@ -295,3 +295,22 @@ def test_shared_matrix_lockstep_kernel_vs_workgroup_kernel(n, m):
     ref = linear_program_batch(f2[:300], A2, b2, want_iters=True)
     assert np.array_equal(bad.numpy('status')[:300], ref.numpy('status'))
     assert np.array_equal(bad.numpy('iters')[:300], ref.numpy('iters'))
+
+
+def test_dual_degenerate_lp_is_retried_with_a_tilted_objective(oracle):
+    """The Chebyshev LP of the cart-pole constraint polytope in (x, u) (370 rows, 24 + 1 variables; the objective sees
+    the radius only) stalls the active-set kernel at its iteration limit; linear_program() then solves it once more
+    with the objective tilted by 1e-9 and reports the value for the objective asked for: the oracle's value, a feasible
+    point, no RuntimeError."""
+    model = golden("c2_model")
+    A = np.hstack((model["Ax"], model["Au"])); b = model["b"]
+    nrm = np.linalg.norm(A, axis=1)
+    Ac = np.hstack((A, nrm[:, None]))
+    f = np.zeros(A.shape[1] + 1); f[-1] = -1.
+    sol = _lp()(f, Ac, b)
+    ref = oracle.linear_program(f, Ac, b)
+    assert sol['min'] is not None and ref['min'] is not None
+    assert abs(sol['min'] - ref['min']) < 1e-6 * max(1., abs(ref['min']))
+    assert (Ac.dot(sol['argmin']) - b).max() < 1e-7
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    assert abs(Polyhedron(A.copy(), b.copy()).radius + ref['min']) < 1e-6

@@ -227,6 +227,7 @@ def mcais(A, X, verbose=False):
             Js.append(X.A.dot(At))
         res = hip_lp.linear_program_batch(-np.vstack(Js), O_inf.A, O_inf.b, want_argmin=False, want_mult=False,
                                           want_active=False)
+        hip_lp.retry_stalled(res, -np.vstack(Js), O_inf.A, O_inf.b)
         st = res.numpy('status')
         if np.any(st == 3):
             raise RuntimeError('Maximum number of iterations reached.')

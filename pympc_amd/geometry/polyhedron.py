@@ -221,6 +221,7 @@ class Polyhedron(object):
             # 1. all facets against the full relaxed set
             res = hip_lp.linear_program_batch(-E, E, f, relax_idx=np.arange(m, dtype=np.int32), relax_val=1.,
                                               want_argmin=False, want_mult=False, want_active=False)
+            hip_lp.retry_stalled(res, -E, E, f, relax_idx=np.arange(m, dtype=np.int32), relax_val=1.)
             v1 = values(res, np.arange(m))
             cand = np.where(v1 < tol)[0]
             sure = np.where(~(v1 < tol))[0]
@@ -229,6 +230,7 @@ class Polyhedron(object):
             if cand.size > 0 and sure.size > 0:
                 res = hip_lp.linear_program_batch(-E[cand], E[sure], f[sure], want_argmin=False, want_mult=False,
                                                   want_active=False)
+                hip_lp.retry_stalled(res, -E[cand], E[sure], f[sure])
                 v2 = values(res, cand)
                 gone = v2 < tol
                 undecided = cand[~gone]

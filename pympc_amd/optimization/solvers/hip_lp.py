@@ -93,6 +93,34 @@ def linear_program(f, A, b, C=None, d=None, tol=TOL):
     return res.sol(0)
 
 
+def retry_stalled(res, f, A, b, relax_idx=None, relax_val=0., tol=TOL):
+    """For callers that read a batch's statuses anyway: the LPs of `res` that ended with the iteration-limit status (a
+    dual-degenerate LP can stall the active-set kernel, see linear_program) are solved once more with their objectives
+    tilted by 1e-9, and `status` / `min` of `res` (host copies) are patched with what comes out -- `min` evaluated with
+    the objective asked for.  f, A, b, relax_idx as given to linear_program_batch.  Returns the number of LPs retried."""
+    st = res.numpy('status')
+    idx = np.where(st == _hip.MAXITER)[0]
+    if idx.size == 0:
+        return 0
+    ft = _hip.to_device(f)[torch.as_tensor(idx, device=_hip.device())]
+    scale = torch.clamp(ft.abs().max(dim=1, keepdim=True).values, min=1.)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    tilt = torch.randn(ft.shape, generator=g, dtype=torch.float64).to(ft.device)
+    A = _hip.to_device(A); b = _hip.to_device(b)
+    ti = torch.as_tensor(idx, device=_hip.device())
+    Ai = A if A.dim() == 2 else A[ti]
+    bi = b if b.dim() == 1 else b[ti]
+    rx = None if relax_idx is None else _hip.to_device(relax_idx, dtype=torch.int32)[ti]
+    again = linear_program_batch(ft + 1.e-9 * scale * tilt, Ai, bi, tol=tol, relax_idx=rx, relax_val=relax_val,
+                                 want_mult=False, want_active=False)
+    st2 = again.numpy('status')
+    val = (ft * again.t['argmin']).sum(dim=1).cpu().numpy()
+    mn = res.numpy('min')
+    st[idx] = st2
+    mn[idx] = np.where(st2 == _hip.OPTIMAL, val, np.nan)
+    return int(idx.size)
+
+
 def nnls_batch(A, b):
     """B NNLS problems min |A_k x - b_k|, x >= 0 in one launch.  A: [rows x cols] (shared) or [B x rows x cols];
     b: [B x rows].  Returns device tensors (x [B x cols], rnorm [B], status [B])."""

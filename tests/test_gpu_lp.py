@@ -314,3 +314,13 @@ def test_dual_degenerate_lp_is_retried_with_a_tilted_objective(oracle):
     assert (Ac.dot(sol['argmin']) - b).max() < 1e-7
     from pympc_amd.geometry.polyhedron import Polyhedron
     assert abs(Polyhedron(A.copy(), b.copy()).radius + ref['min']) < 1e-6
+    # the same for callers of the batched form that read the statuses anyway (minimal_facets, mcais): retry_stalled patches
+    # the host copies of status and min
+    from pympc_amd.optimization.solvers import hip_lp
+    F = np.vstack((f, np.random.RandomState(1).randn(Ac.shape[1])))          # the stalled LP and a generic one
+    res = hip_lp.linear_program_batch(F, Ac, b, want_mult=False, want_active=False)
+    st0 = res.numpy('status').copy(); mn0 = res.numpy('min').copy()
+    if st0[0] == 3:
+        assert hip_lp.retry_stalled(res, F, Ac, b) == 1
+    assert res.numpy('status')[0] == 0 and abs(res.numpy('min')[0] - ref['min']) < 1e-6
+    assert res.numpy('status')[1] == st0[1] and (st0[1] != 0 or res.numpy('min')[1] == mn0[1])

@@ -1,0 +1,406 @@
+// NNLS and the PNNLS reduction for problems of 65 .. 256 rows: one workgroup of 256 threads per problem.
+//
+// The wave kernel of qp_wave.hpp keeps one row per lane, which ends at 64 rows (QPs of up to 63 variables, LPs in the
+// reference's KKT form of pnnls.py:109-124 with 1 + m + n <= 64).  The reference has no such limit
+// (scipy.optimize.nnls, called at /root/reference/pympc/optimization/solvers/pnnls.py:36 and :218, takes any size), so
+// this file states Lawson-Hanson once more with one row per THREAD of a 256-thread workgroup:
+//
+//   * the working matrix stays in device memory, row-major as the caller gave it: every pass over it (dual vector,
+//     Householder application, Givens rotation of two rows) runs thread <-> column, coalesced, with the column-wise
+//     sums kept in one thread -- no reductions in the O(rows x cols) passes;
+//   * vectors over rows (right-hand side, trial solution, reflector) and over columns (x, w, the index permutation and
+//     its inverse) live in LDS; scalars every thread needs come from block reductions of one barrier each;
+//   * the triangular solves stage 32 columns of the factor in LDS at a time and run the reference's column-oriented
+//     back substitution on them (one barrier per unknown);
+//   * control flow is uniform: every decision is taken from LDS values all threads read alike.
+// The algorithm, its tolerances and its selection rules (first maximum of the dual vector in index order, 0.01
+// independence factor, first minimum of the step ratio, itmax = 3 cols) are those of Lawson & Hanson's NNLS (1974,
+// ch. 23), the routine behind the scipy version the reference pins.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "invqr_wave.hpp"
+#include "nnls_raw.hpp"
+
+namespace pympc {
+
+constexpr int kBlkThreads = 256;
+constexpr int kBlkWaves = kBlkThreads / 64;
+constexpr int kBlkRowsMax = 256;   // one row per thread
+constexpr int kBlkTriCols = 32;    // columns of the triangular factor staged in LDS at a time
+
+struct NnlsBlockParams {
+    int rows, cols;
+    int itmax;                 // limit of secondary-loop passes (scipy: 3 cols)
+    const double *A;           // [B x rows x cols] row-major (a_stride = rows*cols) or shared (a_stride 0)
+    long long a_stride;
+    const double *b;           // [B x rows]
+    long long b_stride;
+    const int32_t *skip_rows;  // per problem: the first skip_rows[k] rows count as zero (PNNLS), or null
+    double *work;              // [B x rows x cols] working copy of the matrix
+    double *x;                 // [B x cols]
+    double *rnorm;             // [B] or null
+    int32_t *status;           // [B]
+    int32_t *iters;            // [B x 2] (outer, secondary) or null
+};
+
+__host__ __device__ inline size_t nnls_block_lds_bytes(int rows, int cols)
+{
+    // doubles: b, zz, u [rows] | x, w [cols] | reduction slots and Givens slots [16] | staged factor [kBlkTriCols x rows]
+    // ints: index, pos [cols]
+    return ((size_t)3 * rows + (size_t)2 * cols + 16 + (size_t)kBlkTriCols * rows) * 8 + (size_t)2 * cols * 4;
+}
+
+// Block reductions over 256 threads through alternating LDS slots: reduction k writes slot k & 1, so a writer of
+// reduction k + 2 has passed the barrier of k + 1 and with it every read of reduction k -- one barrier each.
+// Every thread must take part in every reduction, in the same order.
+struct BlockReduce {
+    double *slot;   // 2 x kBlkWaves doubles
+    int phase;
+    __device__ __forceinline__ double *next()
+    {
+        double *s = slot + (phase & 1) * kBlkWaves;
+        ++phase;
+        return s;
+    }
+    __device__ __forceinline__ double sum(double v)
+    {
+        v = wsum(v);
+        double *s = next();
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (s[0] + s[1]) + (s[2] + s[3]);
+    }
+    __device__ __forceinline__ double max(double v)
+    {
+        v = wmax(v);
+        double *s = next();
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return max_raw(max_raw(s[0], s[1]), max_raw(s[2], s[3]));
+    }
+    __device__ __forceinline__ double min(double v)
+    {
+        v = wmin(v);
+        double *s = next();
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return min_raw(min_raw(s[0], s[1]), min_raw(s[2], s[3]));
+    }
+    __device__ __forceinline__ int min_int(int v)
+    {
+        v = wmin_int(v);
+        int *s = reinterpret_cast<int *>(next());
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return ::min(::min(s[0], s[1]), ::min(s[2], s[3]));
+    }
+};
+
+// Lawson-Hanson's G1: the rotation that takes (a, b) to (sig, 0)
+__device__ __forceinline__ void blk_givens(double a, double b, double &c, double &s, double &sig)
+{
+    if (fabs(a) > fabs(b)) {
+        const double xr = b / a, yr = sqrt(1.0 + xr * xr);
+        c = copysign(1.0 / yr, a);
+        s = c * xr;
+        sig = fabs(a) * yr;
+    } else if (b != 0.0) {
+        const double xr = a / b, yr = sqrt(1.0 + xr * xr);
+        s = copysign(1.0 / yr, b);
+        c = s * xr;
+        sig = fabs(b) * yr;
+    } else {
+        sig = 0.0; c = 0.0; s = 1.0;
+    }
+}
+
+// zz[0 .. nsetp) <- solution of the triangular system whose column at position ip is column index[ip] of `a`
+// (rows 0 .. ip); zz holds the right-hand side on entry.  Ends with a barrier.
+__device__ __forceinline__ void blk_trisolve(const double *a, int n, int m, int nsetp, const int *index, double *zz, double *tri)
+{
+    const int t = threadIdx.x;
+    for (int hi = nsetp; hi > 0; hi -= kBlkTriCols) {
+        const int lo = hi > kBlkTriCols ? hi - kBlkTriCols : 0, nc = hi - lo;
+        for (int e = t; e < nc * hi; e += kBlkThreads) {
+            const int c = e / hi, r = e - c * hi;
+            tri[c * m + r] = a[(size_t)r * n + index[lo + c]];
+        }
+        __syncthreads();
+        for (int ip = hi - 1; ip >= lo; --ip) {
+            const double *col = tri + (ip - lo) * m;
+            if (t == ip) zz[ip] = zz[ip] / col[ip];
+            __syncthreads();
+            if (t < ip) zz[t] = fma(-col[t], zz[ip], zz[t]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams P)
+{
+    extern __shared__ double lds[];
+    const int t = threadIdx.x, m = P.rows, n = P.cols;
+    const long long k = blockIdx.x;
+    double *bs = lds, *zz = bs + m, *uu = zz + m, *xs = uu + m, *ws = xs + n, *slots = ws + n;
+    double *gslot = slots + 8;            // 2 x 4 doubles: (c, s, sig) of the rotation in flight
+    double *tri = slots + 16;
+    int *index = reinterpret_cast<int *>(tri + (size_t)kBlkTriCols * m), *pos = index + n;
+    BlockReduce red{slots, 0};
+
+    double *a = P.work + k * (long long)m * n;
+    const double *A = P.A + k * P.a_stride;
+    const int skip = P.skip_rows ? P.skip_rows[k] : 0;
+    for (size_t e = t; e < (size_t)m * n; e += kBlkThreads) a[e] = (int)(e / n) >= skip ? A[e] : 0.0;
+    if (t < m) bs[t] = t >= skip ? P.b[k * P.b_stride + t] : 0.0;
+    for (int j = t; j < n; j += kBlkThreads) { xs[j] = 0.0; ws[j] = 0.0; index[j] = j; pos[j] = j; }
+    __syncthreads();
+
+    const double factor = 0.01;
+    int iter = 0, outer = 0, mode = 0, nsetp = 0;   // P = index[0 .. nsetp), Z = index[nsetp .. n)
+    for (;;) {
+        if (nsetp >= n || nsetp >= m) break;
+        // dual vector on Z
+        for (int j = t; j < n; j += kBlkThreads) {
+            if (pos[j] < nsetp) continue;
+            double sm = 0.0;
+            for (int l = nsetp; l < m; ++l) sm = fma(a[(size_t)l * n + j], bs[l], sm);
+            ws[j] = sm;
+        }
+        __syncthreads();
+        bool accepted = false;
+        int j = -1, izmax = -1;
+        double up = 0.0, newpiv = 0.0, cj = 0.0;
+        for (;;) {
+            // largest positive dual; the first one in index order among equals
+            double best = 0.0;
+            int bpos = 0x7fffffff;
+            for (int c = t; c < n; c += kBlkThreads) {
+                const int p = pos[c];
+                const double w = ws[c];
+                if (p >= nsetp && w > 0.0 && (w > best || (w == best && p < bpos))) { best = w; bpos = p; }
+            }
+            const double wmx = red.max(best);
+            if (!(wmx > 0.0)) break;   // Kuhn-Tucker conditions hold
+            izmax = red.min_int(best == wmx ? bpos : 0x7fffffff);
+            j = index[izmax];
+            // reflector of column j at the pivot row nsetp (H12 in construction mode), without touching the matrix
+            cj = t < m ? a[(size_t)t * n + j] : 0.0;
+            const bool tail = t >= nsetp && t < m;
+            double cl = red.max(tail ? fabs(cj) : 0.0);
+            if (t == nsetp) uu[t] = cj;   // the pivot entry, for everybody
+            up = 0.0;
+            const double sm0 = red.sum(tail && cl > 0.0 ? (cj / cl) * (cj / cl) : 0.0);   // (the barrier also publishes uu[nsetp])
+            const double cjp = uu[nsetp];
+            newpiv = cjp;
+            if (cl > 0.0) {
+                cl *= sqrt(sm0);
+                if (cjp > 0.0) cl = -cl;
+                up = cjp - cl;
+                newpiv = cl;
+            }
+            const double unorm = sqrt(red.sum(t < nsetp ? cj * cj : 0.0));
+            const double t1 = unorm + fabs(newpiv) * factor;
+            bool ok = false;
+            if (t1 - unorm > 0.0) {   // column j is sufficiently independent: would its coefficient be positive?
+                const double bb = up * newpiv;
+                double sm = red.sum(t == nsetp ? bs[t] * up : (t > nsetp && t < m ? bs[t] * cj : 0.0));
+                if (bb >= 0.0) sm = 0.0;
+                else sm /= bb;
+                if (t < m) zz[t] = t == nsetp ? fma(sm, up, bs[t]) : (t > nsetp ? fma(sm, cj, bs[t]) : bs[t]);
+                __syncthreads();
+                ok = zz[nsetp] / newpiv > 0.0;
+            }
+            if (ok) { accepted = true; break; }
+            if (t == 0) ws[j] = 0.0;
+            __syncthreads();
+        }
+        if (!accepted) break;
+        ++outer;
+        // column j moves from Z to P
+        const int piv = nsetp;
+        if (t < m) { bs[t] = zz[t]; uu[t] = t > piv ? cj : 0.0; }
+        if (t == 0) {
+            const int other = index[piv];
+            index[izmax] = other; pos[other] = izmax;
+            index[piv] = j; pos[j] = piv;
+            ws[j] = 0.0;
+        }
+        ++nsetp;
+        __syncthreads();
+        {
+            const double bb = up * newpiv;
+            if (bb < 0.0) {
+                const double binv = 1.0 / bb;
+                for (int c = t; c < n; c += kBlkThreads) {
+                    if (pos[c] < nsetp) continue;
+                    double sm = a[(size_t)piv * n + c] * up;
+                    for (int i = piv + 1; i < m; ++i) sm = fma(a[(size_t)i * n + c], uu[i], sm);
+                    if (sm != 0.0) {
+                        sm *= binv;
+                        a[(size_t)piv * n + c] = fma(sm, up, a[(size_t)piv * n + c]);
+                        for (int i = piv + 1; i < m; ++i) a[(size_t)i * n + c] = fma(sm, uu[i], a[(size_t)i * n + c]);
+                    }
+                }
+            }
+            if (t == piv) a[(size_t)t * n + j] = newpiv;
+            if (t > piv && t < m) a[(size_t)t * n + j] = 0.0;
+        }
+        __syncthreads();
+        blk_trisolve(a, n, m, nsetp, index, zz, tri);   // zz == bs here
+        // secondary loop
+        for (;;) {
+            ++iter;
+            if (iter > P.itmax) { mode = 3; break; }
+            double ratio = 2.0;
+            if (t < nsetp && zz[t] <= 0.0) {
+                const double xl = xs[index[t]];
+                const double r = -xl / (zz[t] - xl);
+                if (r == r) ratio = r;
+            }
+            const double alpha = red.min(ratio);
+            if (alpha == 2.0) break;
+            int jj = red.min_int(ratio == alpha ? t : 0x7fffffff);
+            if (t < nsetp) {
+                const int l = index[t];
+                xs[l] = fma(alpha, zz[t] - xs[l], xs[l]);
+            }
+            __syncthreads();
+            int i = index[jj];
+            for (;;) {
+                // column i leaves P: the columns behind it move up one position, a rotation each
+                if (t == 0) xs[i] = 0.0;
+                for (int jc = jj + 1; jc < nsetp; ++jc) {
+                    const int ii = index[jc];
+                    double *gs = gslot + (jc & 1) * 4;
+                    if (t == (ii & (kBlkThreads - 1))) {
+                        double cc, ss, sig;
+                        blk_givens(a[(size_t)(jc - 1) * n + ii], a[(size_t)jc * n + ii], cc, ss, sig);
+                        gs[0] = cc; gs[1] = ss; gs[2] = sig;
+                    }
+                    __syncthreads();
+                    const double cc = gs[0], ss = gs[1], sig = gs[2];
+                    double *r0 = a + (size_t)(jc - 1) * n, *r1 = a + (size_t)jc * n;
+                    for (int c = t; c < n; c += kBlkThreads) {
+                        if (c == ii) { r0[c] = sig; r1[c] = 0.0; continue; }
+                        const double v0 = r0[c], v1 = r1[c];
+                        r0[c] = fma(cc, v0, ss * v1);
+                        r1[c] = fma(-ss, v0, cc * v1);
+                    }
+                    if (t == 0) {
+                        index[jc - 1] = ii; pos[ii] = jc - 1;
+                        const double v0 = bs[jc - 1], v1 = bs[jc];
+                        bs[jc - 1] = fma(cc, v0, ss * v1);
+                        bs[jc] = fma(-ss, v0, cc * v1);
+                    }
+                }
+                --nsetp;
+                __syncthreads();
+                if (t == 0) { index[nsetp] = i; pos[i] = nsetp; }
+                __syncthreads();
+                // round-off guard: whatever is left in P with a non-positive coefficient leaves too
+                jj = red.min_int(t < nsetp && xs[index[t]] <= 0.0 ? t : 0x7fffffff);
+                if (jj == 0x7fffffff) break;
+                i = index[jj];
+            }
+            if (t < m) zz[t] = bs[t];
+            __syncthreads();
+            blk_trisolve(a, n, m, nsetp, index, zz, tri);
+        }
+        if (mode != 0) break;
+        if (t < nsetp) xs[index[t]] = zz[t];
+        __syncthreads();
+    }
+    const double rn = sqrt(red.sum(t >= nsetp && t < m ? bs[t] * bs[t] : 0.0));
+    for (int c = t; c < n; c += kBlkThreads) P.x[k * (long long)n + c] = xs[c];
+    if (t == 0) {
+        if (P.rnorm) P.rnorm[k] = rn;
+        P.status[k] = mode;
+        if (P.iters) { P.iters[2 * k] = outer; P.iters[2 * k + 1] = iter; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- PNNLS, 65 .. 256 rows
+// pnnls_reduce_kernel of nnls_raw.hpp with one row per thread: Householder QR of B with column pivoting applied to
+// [A | c].  LDS: B (rows x (nu | 1)), the reflector, reduction slots, the permutation.
+__host__ __device__ inline size_t pnnls_block_lds_bytes(int rows, int nu)
+{
+    return ((size_t)rows * (nu | 1) + rows + 8) * 8 + (size_t)(nu + 1) * 4;
+}
+
+__global__ void __launch_bounds__(kBlkThreads) pnnls_reduce_block_kernel(PnnlsParams P)
+{
+    extern __shared__ double lds[];
+    const long long k = blockIdx.x;
+    const int rows = P.rows, cols = P.cols, nu = P.nu, ld = nu | 1, t = threadIdx.x;
+    double *Bs = lds, *vv = Bs + (size_t)rows * ld, *slots = vv + rows;
+    int *perm = reinterpret_cast<int *>(slots + 8);
+    BlockReduce red{slots, 0};
+    const double *A = P.A + k * (long long)rows * cols;
+    double *QA = P.QA + k * (long long)rows * cols;
+    double *Qc = P.Qc + k * (long long)rows;
+    for (int e = t; e < rows * nu; e += kBlkThreads) Bs[(e / nu) * ld + (e % nu)] = P.Bm[k * (long long)rows * nu + e];
+    for (size_t e = t; e < (size_t)rows * cols; e += kBlkThreads) QA[e] = A[e];
+    if (t < rows) Qc[t] = P.c[k * (long long)rows + t];
+    if (t < nu) perm[t] = t;
+    __syncthreads();
+    double norm0 = 0.0;
+    int rank = 0;
+    const int steps = nu < rows ? nu : rows;
+    for (int j = 0; j < steps; ++j) {
+        double s = -1.0;
+        if (t >= j && t < nu) {
+            s = 0.0;
+            for (int i = j; i < rows; ++i) s = fma(Bs[i * ld + t], Bs[i * ld + t], s);
+        }
+        const double smax = red.max(s);
+        if (j == 0) norm0 = smax;
+        if (!(smax > kPnnlsRankTol * kPnnlsRankTol * norm0) || !(smax > 0.0)) break;
+        const int piv = red.min_int(s == smax ? t : 0x7fffffff);
+        if (piv != j) {
+            if (t < rows) {
+                const double v = Bs[t * ld + j];
+                Bs[t * ld + j] = Bs[t * ld + piv];
+                Bs[t * ld + piv] = v;
+            }
+            if (t == 0) { const int q = perm[j]; perm[j] = perm[piv]; perm[piv] = q; }
+        }
+        __syncthreads();
+        const double xi = (t >= j && t < rows) ? Bs[t * ld + j] : 0.0;
+        const double sigma = sqrt(red.sum(xi * xi));
+        const double xj = Bs[j * ld + j];
+        const double alpha = xj > 0.0 ? -sigma : sigma;
+        const double vi = (t == j) ? xi - alpha : xi;
+        const double vtv = red.sum(vi * vi);
+        if (t < rows) vv[t] = vi;
+        __syncthreads();
+        if (vtv > 0.0) {
+            const double f = 2.0 / vtv;
+            if (t > j && t < nu) {
+                double d = 0.0;
+                for (int i = j; i < rows; ++i) d = fma(vv[i], Bs[i * ld + t], d);
+                d *= f;
+                for (int i = j; i < rows; ++i) Bs[i * ld + t] = fma(-d, vv[i], Bs[i * ld + t]);
+            }
+            for (int cidx = t; cidx <= cols; cidx += kBlkThreads) {
+                double *col = cidx < cols ? QA + cidx : Qc;
+                const size_t st = cidx < cols ? (size_t)cols : 1;
+                double d = 0.0;
+                for (int i = j; i < rows; ++i) d = fma(vv[i], col[i * st], d);
+                d *= f;
+                for (int i = j; i < rows; ++i) col[i * st] = fma(-d, vv[i], col[i * st]);
+            }
+        }
+        __syncthreads();
+        if (t == j) Bs[j * ld + j] = alpha;
+        if (t > j && t < rows) Bs[t * ld + j] = 0.0;
+        __syncthreads();
+        rank = j + 1;
+    }
+    for (int e = t; e < rows * nu; e += kBlkThreads) P.Rf[k * (long long)rows * nu + e] = Bs[(e / nu) * ld + (e % nu)];
+    if (t < nu) P.perm[k * nu + t] = perm[t];
+    if (t == 0) P.rank[k] = rank;
+}
+
+}  // namespace pympc

@@ -13,6 +13,7 @@
 #include "lp_block.hpp"
 #include "lp_tile.hpp"
 #include "nnls_raw.hpp"
+#include "nnls_block.hpp"
 #include "point_location.hpp"
 #include "qp_prepare.hpp"
 #include "qp_wave.hpp"
@@ -542,21 +543,41 @@ int pympc_mpqp_solve_batch_static(int n, int m, int p, const double *ws, const d
 size_t pympc_nnls_workspace_doubles(int rows, int cols, int64_t B)
 {
     const int R = rows < 2 ? 2 : rows;
-    if (rows < 1 || cols < 1 || R - 1 > kNMax || cols > kMMax || B < 0) return 0;
+    if (rows < 1 || cols < 1 || rows > kBlkRowsMax || cols > kMMax || B < 0) return 0;
+    if (R - 1 > kNMax) return (size_t)rows * cols * (size_t)B + 32;   // nnls_block_kernel: a working copy of each matrix
     return (ws_layout(R - 1, cols, 0).total + (size_t)R) * (size_t)B + 32;
 }
+
+namespace {
+// 65 .. 256 rows: one workgroup per problem (nnls_block.hpp)
+int launch_nnls_block(int rows, int cols, int64_t B, const double *A, int64_t a_stride, const double *b, const int32_t *skip_rows,
+                      double *work, double *x, double *rnorm, int32_t *status, int32_t *iters, hipStream_t st)
+{
+    NnlsBlockParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.rows = rows; Q.cols = cols;
+    Q.itmax = (int)std::min<long long>(g_tune.nnls_itmax_factor.load() * (long long)cols, 0x7fffffffLL);
+    Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = rows; Q.skip_rows = skip_rows;
+    Q.work = work; Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
+    const size_t lds = nnls_block_lds_bytes(rows, cols);
+    if (int rc = allow_lds(nnls_block_kernel, lds)) return rc;
+    hipLaunchKernelGGL(nnls_block_kernel, dim3((unsigned)B), dim3(kBlkThreads), lds, st, Q);
+    return check_launch("nnls_block_kernel");
+}
+}  // namespace
 
 int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_stride, const double *b, double *ws, double *x,
                      double *rnorm, int32_t *status, int32_t *iters, void *stream)
 {
     if (rows < 1 || cols < 1 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_nnls_batch: bad shape %d x %d", rows, cols);
     const int R = rows < 2 ? 2 : rows;
-    if (R - 1 > kNMax) return fail(PYMPC_ERR_UNSUPPORTED, "rows=%d exceeds the wave kernel's limit of %d rows", rows, kNMax + 1);
-    if (cols > kMMax) return fail(PYMPC_ERR_UNSUPPORTED, "cols=%d exceeds the wave kernel's limit of %d columns", cols, kMMax);
+    if (rows > kBlkRowsMax) return fail(PYMPC_ERR_UNSUPPORTED, "rows=%d exceeds the limit of %d rows", rows, kBlkRowsMax);
+    if (cols > kMMax) return fail(PYMPC_ERR_UNSUPPORTED, "cols=%d exceeds the limit of %d columns", cols, kMMax);
     if (a_stride != 0 && a_stride < (int64_t)rows * cols) return fail(PYMPC_ERR_ARG, "a_stride %lld < rows*cols", (long long)a_stride);
     if (B == 0) return 0;
     if (!A || !b || !ws || !x || !status) return fail(PYMPC_ERR_ARG, "pympc_nnls_batch: null pointer");
     if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+    if (R - 1 > kNMax) return launch_nnls_block(rows, cols, B, A, a_stride, b, nullptr, ws, x, rnorm, status, iters, (hipStream_t)stream);
     const WsLayout L = ws_layout(R - 1, cols, 0);
     NnlsPrepParams Q;
     memset(&Q, 0, sizeof(Q));
@@ -574,7 +595,7 @@ int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_s
 
 size_t pympc_pnnls_workspace_doubles(int rows, int cols, int nu, int64_t B)
 {
-    if (rows < 1 || rows > 64 || cols < 1 || cols > kMMax || nu < 0 || nu > 64 || B < 0) return 0;
+    if (rows < 1 || rows > kBlkRowsMax || cols < 1 || cols > kMMax || nu < 0 || nu > 64 || B < 0) return 0;
     const size_t nn = pympc_nnls_workspace_doubles(rows, cols, B);
     if (nn == 0) return 0;
     return nn + ((size_t)rows * cols + rows + (size_t)rows * nu + nu + 2) * (size_t)B + 32;
@@ -584,9 +605,9 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
                       double *v, double *u, double *rnorm, int32_t *status, int32_t *iters, void *stream)
 {
     if (rows < 1 || cols < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: bad shape");
-    if (rows > 64 || nu > 64 || cols > kMMax)
-        return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of 64 rows, 64 free and %d sign-constrained variables",
-                    rows, cols, nu, kMMax);
+    if (rows > kBlkRowsMax || nu > 64 || cols > kMMax)
+        return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of %d rows, 64 free and %d sign-constrained variables",
+                    rows, cols, nu, kBlkRowsMax, kMMax);
     if (B == 0) return 0;
     if (!A || !c || !ws || !v || !status || (nu > 0 && (!Bm || !u))) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: null pointer");
     if (nu == 0) return pympc_nnls_batch(rows, cols, B, A, (int64_t)rows * cols, c, ws, v, rnorm, status, iters, stream);
@@ -602,6 +623,15 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
     R.rank = R.perm + (size_t)nu * B;
     R.v = v; R.u = u;
     hipStream_t st = (hipStream_t)stream;
+    if (rows > 64) {   // one row per thread of a workgroup instead of one per lane (nnls_block.hpp)
+        const size_t ldsb = pnnls_block_lds_bytes(rows, nu);
+        if (int rc = allow_lds(pnnls_reduce_block_kernel, ldsb)) return rc;
+        hipLaunchKernelGGL(pnnls_reduce_block_kernel, dim3((unsigned)B), dim3(kBlkThreads), ldsb, st, R);
+        if (int rc = check_launch("pnnls_reduce_block_kernel")) return rc;
+        if (int rc = launch_nnls_block(rows, cols, B, R.QA, (int64_t)rows * cols, R.Qc, R.rank, ws, v, rnorm, status, iters, st)) return rc;
+        hipLaunchKernelGGL(pnnls_recover_kernel, dim3((unsigned)B), dim3(64), (64 + 64 * 65 + 64) * 8, st, R);
+        return check_launch("pnnls_recover_kernel");
+    }
     const size_t lds1 = pnnls_lds_doubles(rows, nu) * 8;
     hipLaunchKernelGGL(pnnls_reduce_kernel, dim3((unsigned)B), dim3(64), lds1, st, R);
     if (int rc = check_launch("pnnls_reduce_kernel")) return rc;

@@ -243,13 +243,15 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
 /* -------------------------------------------------------------------------------------------------
  * Raw NNLS and PNNLS: the two numerical cores under the QP / LP transformations.
  *
- * pympc_nnls_batch: B problems  min |A_k x - b_k|  s.t. x >= 0  of equal shape (rows <= 64, cols <= 2048).
+ * pympc_nnls_batch: B problems  min |A_k x - b_k|  s.t. x >= 0  of equal shape (rows <= 256, cols <= 2048; up to
+ * 64 rows one wavefront per problem with a row per lane, from 65 rows one workgroup per problem with a row per
+ * thread, csrc/nnls_block.hpp -- same algorithm, same selection rules).
  * Reference: scipy.optimize.nnls(A, b) as called at pympc/optimization/solvers/pnnls.py:36 and :218 (third party,
  * pinned scipy<=1.11.4: Lawson-Hanson; maxiter = 3 cols).  A [B x rows x cols] (a_stride = rows*cols) or [rows x cols]
  * shared (a_stride 0); b [B x rows].  Outputs x [B x cols], rnorm [B] = |A x - b| (may be NULL), status [B]
  * (PYMPC_OPTIMAL / PYMPC_MAXITER: scipy raises RuntimeError there), iters [B x 2] (may be NULL).
  *
- * pympc_pnnls_batch: B problems  min |A_k v + B_k u - c_k|  s.t. v >= 0  (rows <= 64, cols <= 2048, nu <= 64).
+ * pympc_pnnls_batch: B problems  min |A_k v + B_k u - c_k|  s.t. v >= 0  (rows <= 256, cols <= 2048, nu <= 64).
  * Reference: pnnls(A, B, c) of pympc/optimization/solvers/pnnls.py:5-39 (returns v, u, r); the reference projects
  * with the dense matrix I - B pinv(B) (:30-33), here u is eliminated by a column-pivoted Householder QR of B (same
  * residual; u is the minimum-norm solution when B is rank deficient, as pinv gives).  A [B x rows x cols],

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.environ.get("PYMPC_HIP_LIB") or os.path.join(LIB_DIR, "libpympc_hip.so")   # (override: debug builds)
 SOURCES = ["pympc_hip.hip"]
-HEADERS = ["ws_layout.hpp", "qp_wave.hpp", "qp_screen.hpp", "qp_gram.hpp", "nnls_raw.hpp", "nnls_block.hpp", "qp_prepare.hpp", "point_location.hpp", "lp_block.hpp", "lp_tile.hpp", "invqr_wave.hpp", "condense.hpp",
+HEADERS = ["ws_layout.hpp", "qp_wave.hpp", "qp_screen.hpp", "qp_gram.hpp", "nnls_raw.hpp", "nnls_block.hpp", "qp_block.hpp", "qp_prepare.hpp", "point_location.hpp", "lp_block.hpp", "lp_tile.hpp", "invqr_wave.hpp", "condense.hpp",
            os.path.join("..", "..", "include", "pympc_hip.h")]
 
 

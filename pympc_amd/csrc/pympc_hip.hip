@@ -14,6 +14,7 @@
 #include "lp_tile.hpp"
 #include "nnls_raw.hpp"
 #include "nnls_block.hpp"
+#include "qp_block.hpp"
 #include "point_location.hpp"
 #include "qp_prepare.hpp"
 #include "qp_wave.hpp"
@@ -550,14 +551,14 @@ size_t pympc_nnls_workspace_doubles(int rows, int cols, int64_t B)
 
 namespace {
 // 65 .. 256 rows: one workgroup per problem (nnls_block.hpp)
-int launch_nnls_block(int rows, int cols, int64_t B, const double *A, int64_t a_stride, const double *b, const int32_t *skip_rows,
+int launch_nnls_block(int rows, int cols, int64_t B, const double *A, int64_t a_stride, const double *b, int64_t b_stride, const int32_t *skip_rows,
                       double *work, double *x, double *rnorm, int32_t *status, int32_t *iters, hipStream_t st)
 {
     NnlsBlockParams Q;
     memset(&Q, 0, sizeof(Q));
     Q.rows = rows; Q.cols = cols;
     Q.itmax = (int)std::min<long long>(g_tune.nnls_itmax_factor.load() * (long long)cols, 0x7fffffffLL);
-    Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = rows; Q.skip_rows = skip_rows;
+    Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = b_stride; Q.skip_rows = skip_rows;
     Q.work = work; Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
     const size_t lds = nnls_block_lds_bytes(rows, cols);
     if (int rc = allow_lds(nnls_block_kernel, lds)) return rc;
@@ -577,7 +578,7 @@ int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_s
     if (B == 0) return 0;
     if (!A || !b || !ws || !x || !status) return fail(PYMPC_ERR_ARG, "pympc_nnls_batch: null pointer");
     if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
-    if (R - 1 > kNMax) return launch_nnls_block(rows, cols, B, A, a_stride, b, nullptr, ws, x, rnorm, status, iters, (hipStream_t)stream);
+    if (R - 1 > kNMax) return launch_nnls_block(rows, cols, B, A, a_stride, b, rows, nullptr, ws, x, rnorm, status, iters, (hipStream_t)stream);
     const WsLayout L = ws_layout(R - 1, cols, 0);
     NnlsPrepParams Q;
     memset(&Q, 0, sizeof(Q));
@@ -628,7 +629,7 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
         if (int rc = allow_lds(pnnls_reduce_block_kernel, ldsb)) return rc;
         hipLaunchKernelGGL(pnnls_reduce_block_kernel, dim3((unsigned)B), dim3(kBlkThreads), ldsb, st, R);
         if (int rc = check_launch("pnnls_reduce_block_kernel")) return rc;
-        if (int rc = launch_nnls_block(rows, cols, B, R.QA, (int64_t)rows * cols, R.Qc, R.rank, ws, v, rnorm, status, iters, st)) return rc;
+        if (int rc = launch_nnls_block(rows, cols, B, R.QA, (int64_t)rows * cols, R.Qc, rows, R.rank, ws, v, rnorm, status, iters, st)) return rc;
         hipLaunchKernelGGL(pnnls_recover_kernel, dim3((unsigned)B), dim3(64), (64 + 64 * 65 + 64) * 8, st, R);
         return check_launch("pnnls_recover_kernel");
     }
@@ -657,15 +658,56 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
 
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)
 {
-    if (n < 1 || m < 1 || n > kNMax || m > kMMax || B < 0) return 0;
+    if (n < 1 || m < 1 || n > kQpBlockNMax || m > kMMax || B < 0) return 0;
+    if (n > kNMax) {   // qp_block.hpp: factors and NNLS matrix per problem, the NNLS kernel's working copy, y, scalars
+        const size_t per = qp_block_layout(n, m).total + (size_t)(n + 1) * m + (size_t)m + 4;
+        return per * (size_t)B + (size_t)n + 2 + 32;
+    }
     // per-problem prepared workspace + one int32 prepare status per problem (stored after the workspaces)
     return ws_layout(n, m, 0).total * (size_t)B + ((size_t)B + 1) / 2 + 32;
 }
+
+namespace {
+// 64 .. 255 variables: one workgroup per problem (qp_block.hpp)
+int qp_block_solve(int n, int m, int64_t B, const double *H, int64_t h_stride, const double *f, const double *A, int64_t a_stride,
+                   const double *b, double tol, double *ws, double *argmin, double *vmin, double *mult, uint32_t *active,
+                   int32_t *status, int32_t *iters, hipStream_t st)
+{
+    const QpBlockLayout L = qp_block_layout(n, m);
+    QpBlockParams P;
+    memset(&P, 0, sizeof(P));
+    P.n = n; P.m = m; P.H = H; P.h_stride = h_stride; P.f = f; P.A = A; P.a_stride = a_stride; P.b = b; P.tol = tol;
+    P.ws = ws;
+    double *work = ws + L.total * (size_t)B;               // [B x (n + 1) x m]
+    P.y = work + (size_t)(n + 1) * m * (size_t)B;          // [B x m]
+    P.rn = P.y + (size_t)m * (size_t)B;                    // [B]
+    P.bn = P.rn + (size_t)B;                               // [n + 1] (+ 1 pad)
+    P.nnls_status = reinterpret_cast<int32_t *>(P.bn + (((size_t)n + 2) & ~(size_t)1));   // [B], then iters [2B], notpd [B]
+    P.nnls_iters = P.nnls_status + (size_t)B;
+    P.notpd = P.nnls_iters + 2 * (size_t)B;
+    P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
+    hipLaunchKernelGGL(qp_block_prepare_kernel, dim3((unsigned)B), dim3(kBlkThreads), 0, st, P);
+    if (int rc = check_launch("qp_block_prepare_kernel")) return rc;
+    if (int rc = launch_nnls_block(n + 1, m, B, ws + L.An, (int64_t)L.total, P.bn, 0, nullptr, work, P.y, P.rn, P.nnls_status,
+                                   P.nnls_iters, st))
+        return rc;
+    hipLaunchKernelGGL(qp_block_recover_kernel, dim3((unsigned)B), dim3(kBlkThreads), 0, st, P);
+    return check_launch("qp_block_recover_kernel");
+}
+}  // namespace
 
 int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_stride, const double *f, const double *A,
                          int64_t a_stride, const double *b, double tol, double *ws, double *argmin, double *vmin,
                          double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream)
 {
+    if (n > kNMax && n <= kQpBlockNMax && m >= 1 && m <= kMMax) {
+        if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: negative batch size");
+        if (B == 0) return 0;
+        if (!H || !f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: null pointer");
+        if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
+        return qp_block_solve(n, m, B, H, h_stride, f, A, a_stride, b, tol, ws, argmin, vmin, mult, active, status, iters,
+                              (hipStream_t)stream);
+    }
     if (int rc = check_shape(n, m, 0)) return rc;
     if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: negative batch size");
     if (B == 0) return 0;

@@ -116,10 +116,24 @@ class PreparedMpqp(object):
         t = _hip.to_device
         self._inputs = [t(Huu), t(Hux), t(Hxx), t(fu), t(fx), t(Au), t(Ax), t(b)]
         nd = lib.pympc_mpqp_workspace_doubles(self.n, self.m, self.p)
+        self.large = False
         if nd == 0:
             nmax, mmax = _hip.limits()
-            raise NotImplementedError('mpQP with n=%d, m=%d is outside the wave kernel limits (n<=%d, m<=%d)'
-                                      % (self.n, self.m, nmax, mmax))
+            if self.n <= nmax or lib.pympc_qp_workspace_doubles(self.n, self.m, 1) == 0:
+                raise NotImplementedError('mpQP with n=%d, m=%d is outside the kernel limits (n<=%d prepared once, n<=255 '
+                                          'solved per state, m<=%d)' % (self.n, self.m, nmax, mmax))
+            # 64 .. 255 variables: no prepared form (the wave kernel's factors live in LDS); every state is solved as
+            # a QP of its own by the workgroup-per-problem kernels of csrc/qp_block.hpp (solve_batch below)
+            self.large = True
+            self.g = float(g)
+            self.ws = None
+            self.cuts = None
+            self._seeded = True
+            st = quadratic_program_batch(self._inputs[0], self._inputs[3].reshape(1, -1), self._inputs[5],
+                                         self._inputs[7].reshape(1, -1), want_mult=False, want_active=False).t['status']
+            if int(st.item()) == _hip.NOT_PD:
+                raise np.linalg.LinAlgError('Matrix is not positive definite')
+            return
         self.ws = torch.empty(nd, dtype=torch.float64, device=self.dev)
         self.ws_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         Huu_, Hux_, Hxx_, fu_, fx_, Au_, Ax_, b_ = self._inputs
@@ -289,6 +303,21 @@ class PreparedMpqp(object):
             raise ValueError('X must be [B x %d]' % self.p)
         B = X.shape[0]
         n_out = self.n if n_out is None else n_out
+        if self.large:
+            if out is not None:
+                raise NotImplementedError('preallocated outputs are for the prepared form (n <= 63)')
+            Huu, Hux, Hxx, fu, fx, Au, Ax, b = self._inputs
+            F = (fu.reshape(1, -1) + X.matmul(Hux.reshape(self.n, self.p).t())).contiguous()     # f(x) = fu + Hux x
+            Bv = (b.reshape(1, -1) - X.matmul(Ax.reshape(self.m, self.p).t())).contiguous()      # b(x) = b - Ax x
+            res = quadratic_program_batch(Huu, F, Au, Bv, tol=tol, want_mult=want_mult, want_active=want_active,
+                                          want_iters=want_iters)
+            t_ = res.t
+            if want_min:   # + x'Hxx x / 2 + fx'x + g (parametric_programs.py:171-173)
+                t_['min'] = t_['min'] + .5 * (X.matmul(Hxx.reshape(self.p, self.p)) * X).sum(dim=1) + X.matmul(fx.reshape(-1)) + self.g
+            else:
+                t_['min'] = None
+            t_['argmin'] = t_['argmin'][:, :n_out].contiguous() if n_out > 0 else None
+            return BatchResult(self.m, **t_)
         if out is None:
             out = _alloc_outputs(B, n_out, self.m, self.dev, want_mult, want_active, want_iters, want_min)
         cuts = (self.cuts if cuts_table is None else cuts_table) if use_cuts else None
@@ -320,8 +349,8 @@ def quadratic_program_batch(H, f, A, b, tol=TOL, n_eq=0, want_mult=True, want_ac
     nd = lib.pympc_qp_workspace_doubles(n, m, B)
     if nd == 0:
         nmax, mmax = _hip.limits()
-        raise NotImplementedError('QP with n=%d, m=%d is outside the wave kernel limits (n<=%d, m<=%d)'
-                                  % (n, m, nmax, mmax))
+        raise NotImplementedError('QP with n=%d, m=%d is outside the kernel limits (n<=%d on the wave kernel, n<=255 on the '
+                                  'workgroup kernel of csrc/qp_block.hpp, m<=%d)' % (n, m, nmax, mmax))
     ws = torch.empty(nd, dtype=torch.float64, device=dev)
     out = _alloc_outputs(B, n, m, dev, want_mult, want_active, want_iters)
     _hip.check(lib.pympc_qp_solve_batch(n, m, B, _hip.ptr(H), h_stride, _hip.ptr(f), _hip.ptr(A), a_stride, _hip.ptr(b),

@@ -167,6 +167,8 @@ int pympc_mpqp_solve_batch_static(int n, int m, int p, const double *ws, const d
  * Reference: pympc/optimization/solvers/pnnls.py:149-241 once per problem (programs.py:57-105); callers
  * polyhedron.py:523 (empty), controllers.py:668-680 + parametric_programs.py:173 (get_mpqp(ms).solve).
  * H [B x n x n] (or [n x n] with h_stride 0), f [B x n], A [B x m x n] (a_stride 0: shared), b [B x m].
+ * n <= 63: one wavefront per problem (pympc_hip_limits); 64 <= n <= 255 (m <= 2048): one workgroup per problem with
+ * the factors in device memory (csrc/qp_block.hpp) -- same outputs, same statuses (PYMPC_NOT_PD included).
  * ------------------------------------------------------------------------------------------------- */
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B);
 

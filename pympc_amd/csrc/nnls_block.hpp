@@ -116,6 +116,38 @@ __device__ __forceinline__ void blk_givens(double a, double b, double &c, double
     }
 }
 
+// Column passes of one thread over rows l0 .. m of column j (stride n): the loads of kBlkUnroll rows are issued together --
+// a loop of one load and one FMA pays the whole memory latency per row (one workgroup per problem: nothing else hides it).
+#ifndef PYMPC_BLK_UNROLL
+#define PYMPC_BLK_UNROLL 8
+#endif
+constexpr int kBlkUnroll = PYMPC_BLK_UNROLL;
+__device__ __forceinline__ double blk_col_dot(const double *a, int n, int j, int l0, int m, const double *vec, double sm)
+{
+    int l = l0;
+    for (; l + kBlkUnroll <= m; l += kBlkUnroll) {
+        double v[kBlkUnroll];
+#pragma unroll
+        for (int u = 0; u < kBlkUnroll; ++u) v[u] = a[(size_t)(l + u) * n + j];
+#pragma unroll
+        for (int u = 0; u < kBlkUnroll; ++u) sm = fma(v[u], vec[l + u], sm);
+    }
+    for (; l < m; ++l) sm = fma(a[(size_t)l * n + j], vec[l], sm);
+    return sm;
+}
+__device__ __forceinline__ void blk_col_axpy(double *a, int n, int j, int l0, int m, const double *vec, double sm)
+{
+    int l = l0;
+    for (; l + kBlkUnroll <= m; l += kBlkUnroll) {
+        double v[kBlkUnroll];
+#pragma unroll
+        for (int u = 0; u < kBlkUnroll; ++u) v[u] = a[(size_t)(l + u) * n + j];
+#pragma unroll
+        for (int u = 0; u < kBlkUnroll; ++u) a[(size_t)(l + u) * n + j] = fma(sm, vec[l + u], v[u]);
+    }
+    for (; l < m; ++l) a[(size_t)l * n + j] = fma(sm, vec[l], a[(size_t)l * n + j]);
+}
+
 // zz[0 .. nsetp) <- solution of the triangular system whose column at position ip is column index[ip] of `a`
 // (rows 0 .. ip); zz holds the right-hand side on entry.  Ends with a barrier.
 __device__ __forceinline__ void blk_trisolve(const double *a, int n, int m, int nsetp, const int *index, double *zz, double *tri)
@@ -123,23 +155,57 @@ __device__ __forceinline__ void blk_trisolve(const double *a, int n, int m, int 
     const int t = threadIdx.x;
     for (int hi = nsetp; hi > 0; hi -= kBlkTriCols) {
         const int lo = hi > kBlkTriCols ? hi - kBlkTriCols : 0, nc = hi - lo;
-        for (int e = t; e < nc * hi; e += kBlkThreads) {
-            const int c = e / hi, r = e - c * hi;
-            tri[c * m + r] = a[(size_t)r * n + index[lo + c]];
+        const int ne = nc * hi;
+        for (int e0 = t; e0 < ne; e0 += 8 * kBlkThreads) {   // (eight gathers in flight per thread)
+            double v[8];
+            int at[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * kBlkThreads;
+                const int c = e < ne ? e / hi : 0, r = e < ne ? e - c * hi : 0;
+                at[u] = c * m + r;
+                v[u] = a[(size_t)r * n + index[lo + c]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * kBlkThreads < ne) tri[at[u]] = v[u];
         }
         __syncthreads();
-        for (int ip = hi - 1; ip >= lo; --ip) {
-            const double *col = tri + (ip - lo) * m;
-            if (t == ip) zz[ip] = zz[ip] / col[ip];
-            __syncthreads();
-            if (t < ip) zz[t] = fma(-col[t], zz[ip], zz[t]);
+        // The diagonal block in ONE wavefront, a lane per row: its nc dependent steps then cost a cross-lane read, a
+        // multiplication and an FMA each -- no barrier, and the division is taken out of the chain (reciprocals of the
+        // nc pivots at once: z * (1 / d) instead of z / d, within an ulp of it).
+        if (t < 64) {
+            const int row = lo + t;
+            double z = t < nc ? zz[row] : 0.0;
+            const double rd = t < nc ? 1.0 / tri[t * m + row] : 0.0;
+            for (int c = nc - 1; c >= 0; --c) {
+                const double zi = lane_f64(z, c) * lane_f64(rd, c);
+                if (t == c) z = zi;
+                if (t < c) z = fma(-tri[c * m + row], zi, z);
+            }
+            if (t < nc) zz[row] = z;
+        }
+        __syncthreads();
+        // the rows above it: the same updates in the same (descending) order, all columns of the block in one go
+        if (t < lo) {
+            double z = zz[t];
+            for (int c = nc - 1; c >= 0; --c) z = fma(-tri[c * m + t], zz[lo + c], z);
+            zz[t] = z;
         }
         __syncthreads();
     }
 }
 
+#ifdef PYMPC_BLK_PROFILE
+#define BLK_TICK(slot) { const long long now_ = wall_clock64(); prof_[slot] += now_ - last_; last_ = now_; }
+#else
+#define BLK_TICK(slot)
+#endif
 __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams P)
 {
+#ifdef PYMPC_BLK_PROFILE
+    long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = wall_clock64();
+#endif
     extern __shared__ double lds[];
     const int t = threadIdx.x, m = P.rows, n = P.cols;
     const long long k = blockIdx.x;
@@ -164,11 +230,10 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
         // dual vector on Z
         for (int j = t; j < n; j += kBlkThreads) {
             if (pos[j] < nsetp) continue;
-            double sm = 0.0;
-            for (int l = nsetp; l < m; ++l) sm = fma(a[(size_t)l * n + j], bs[l], sm);
-            ws[j] = sm;
+            ws[j] = blk_col_dot(a, n, j, nsetp, m, bs, 0.0);
         }
         __syncthreads();
+        BLK_TICK(0)
         bool accepted = false;
         int j = -1, izmax = -1;
         double up = 0.0, newpiv = 0.0, cj = 0.0;
@@ -216,6 +281,7 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
             if (t == 0) ws[j] = 0.0;
             __syncthreads();
         }
+        BLK_TICK(1)
         if (!accepted) break;
         ++outer;
         // column j moves from Z to P
@@ -235,12 +301,12 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
                 const double binv = 1.0 / bb;
                 for (int c = t; c < n; c += kBlkThreads) {
                     if (pos[c] < nsetp) continue;
-                    double sm = a[(size_t)piv * n + c] * up;
-                    for (int i = piv + 1; i < m; ++i) sm = fma(a[(size_t)i * n + c], uu[i], sm);
+                    const double ap = a[(size_t)piv * n + c];
+                    double sm = blk_col_dot(a, n, c, piv + 1, m, uu, ap * up);
                     if (sm != 0.0) {
                         sm *= binv;
-                        a[(size_t)piv * n + c] = fma(sm, up, a[(size_t)piv * n + c]);
-                        for (int i = piv + 1; i < m; ++i) a[(size_t)i * n + c] = fma(sm, uu[i], a[(size_t)i * n + c]);
+                        a[(size_t)piv * n + c] = fma(sm, up, ap);
+                        blk_col_axpy(a, n, c, piv + 1, m, uu, sm);
                     }
                 }
             }
@@ -248,7 +314,9 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
             if (t > piv && t < m) a[(size_t)t * n + j] = 0.0;
         }
         __syncthreads();
+        BLK_TICK(2)
         blk_trisolve(a, n, m, nsetp, index, zz, tri);   // zz == bs here
+        BLK_TICK(3)
         // secondary loop
         for (;;) {
             ++iter;
@@ -306,12 +374,19 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
             }
             if (t < m) zz[t] = bs[t];
             __syncthreads();
+            BLK_TICK(4)
             blk_trisolve(a, n, m, nsetp, index, zz, tri);
+            BLK_TICK(3)
         }
         if (mode != 0) break;
         if (t < nsetp) xs[index[t]] = zz[t];
         __syncthreads();
     }
+#ifdef PYMPC_BLK_PROFILE
+    if (t == 0 && k == 0)
+        printf("nnls_block %d x %d: outer %d secondary %d | us: dual %lld select %lld apply %lld trisolve %lld givens+ratio %lld\n", m, n, outer, iter,
+               prof_[0] / 100, prof_[1] / 100, prof_[2] / 100, prof_[3] / 100, prof_[4] / 100);
+#endif
     const double rn = sqrt(red.sum(t >= nsetp && t < m ? bs[t] * bs[t] : 0.0));
     for (int c = t; c < n; c += kBlkThreads) P.x[k * (long long)n + c] = xs[c];
     if (t == 0) {

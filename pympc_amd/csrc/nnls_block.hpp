@@ -10,8 +10,11 @@
 //     sums kept in one thread -- no reductions in the O(rows x cols) passes;
 //   * vectors over rows (right-hand side, trial solution, reflector) and over columns (x, w, the index permutation and
 //     its inverse) live in LDS; scalars every thread needs come from block reductions of one barrier each;
-//   * the triangular solves stage 32 columns of the factor in LDS at a time and run the reference's column-oriented
-//     back substitution on them (one barrier per unknown);
+//   * the columns of the matrix that are in the set P have a second home: a packed, column-contiguous copy of the
+//     triangular factor in device memory (a slot per column).  The triangular solves stage 32 of its columns in LDS at
+//     a time (coalesced) and run the reference's column-oriented back substitution on them; when a column leaves P the
+//     rotations are generated on that copy (a thread per column, the chain of dependent rotations through LDS) and then
+//     applied to all other columns of the matrix in one pass without barriers;
 //   * control flow is uniform: every decision is taken from LDS values all threads read alike.
 // The algorithm, its tolerances and its selection rules (first maximum of the dual vector in index order, 0.01
 // independence factor, first minimum of the step ratio, itmax = 3 cols) are those of Lawson & Hanson's NNLS (1974,
@@ -39,6 +42,7 @@ struct NnlsBlockParams {
     long long b_stride;
     const int32_t *skip_rows;  // per problem: the first skip_rows[k] rows count as zero (PNNLS), or null
     double *work;              // [B x rows x cols] working copy of the matrix
+    double *factor;            // [B x rows x rows] the triangular factor, a slot of `rows` doubles per column in P
     double *x;                 // [B x cols]
     double *rnorm;             // [B] or null
     int32_t *status;           // [B]
@@ -47,9 +51,9 @@ struct NnlsBlockParams {
 
 __host__ __device__ inline size_t nnls_block_lds_bytes(int rows, int cols)
 {
-    // doubles: b, zz, u [rows] | x, w [cols] | reduction slots and Givens slots [16] | staged factor [kBlkTriCols x rows]
-    // ints: index, pos [cols]
-    return ((size_t)3 * rows + (size_t)2 * cols + 16 + (size_t)kBlkTriCols * rows) * 8 + (size_t)2 * cols * 4;
+    // doubles: b, zz, u [rows] | x, w [cols] | reduction slots [8] | rotations c, s [rows] | staged factor [kBlkTriCols x rows]
+    // ints: index, pos [cols], slotpos [rows]
+    return ((size_t)(5 + kBlkTriCols) * rows + (size_t)2 * cols + 8) * 8 + (((size_t)2 * cols + rows) * 4 + 7) / 8 * 8;
 }
 
 // Block reductions over 256 threads through alternating LDS slots: reduction k writes slot k & 1, so a writer of
@@ -116,6 +120,19 @@ __device__ __forceinline__ void blk_givens(double a, double b, double &c, double
     }
 }
 
+// The same rotation as c = a / r, s = b / r, sig = r with one reciprocal square root: the chain of dependent rotations
+// of a deletion runs through this, so its latency counts.  Outside [1e-280, 1e280] (and for a = b = 0) the exact form.
+__device__ __forceinline__ void blk_givens_fast(double a, double b, double &c, double &s, double &sig)
+{
+    const double r2 = fma(a, a, b * b);
+    if (r2 > 1e-280 && r2 < 1e280) {
+        const double inv = rsqrt(r2);
+        c = a * inv; s = b * inv; sig = r2 * inv;
+    } else {
+        blk_givens(a, b, c, s, sig);
+    }
+}
+
 // Column passes of one thread over rows l0 .. m of column j (stride n): the loads of kBlkUnroll rows are issued together --
 // a loop of one load and one FMA pays the whole memory latency per row (one workgroup per problem: nothing else hides it).
 #ifndef PYMPC_BLK_UNROLL
@@ -148,40 +165,41 @@ __device__ __forceinline__ void blk_col_axpy(double *a, int n, int j, int l0, in
     for (; l < m; ++l) a[(size_t)l * n + j] = fma(sm, vec[l], a[(size_t)l * n + j]);
 }
 
-// zz[0 .. nsetp) <- solution of the triangular system whose column at position ip is column index[ip] of `a`
-// (rows 0 .. ip); zz holds the right-hand side on entry.  Ends with a barrier.
-__device__ __forceinline__ void blk_trisolve(const double *a, int n, int m, int nsetp, const int *index, double *zz, double *tri)
+// zz[0 .. nsetp) <- solution of the triangular system whose column at position ip sits in slot slotpos[ip] of the
+// packed factor Rs (rows 0 .. ip); zz holds the right-hand side on entry.  Ends with a barrier.
+__device__ __forceinline__ void blk_trisolve(const double *Rs, int m, int nsetp, const int *slotpos, double *zz, double *tri)
 {
     const int t = threadIdx.x;
     for (int hi = nsetp; hi > 0; hi -= kBlkTriCols) {
         const int lo = hi > kBlkTriCols ? hi - kBlkTriCols : 0, nc = hi - lo;
-        const int ne = nc * hi;
-        for (int e0 = t; e0 < ne; e0 += 8 * kBlkThreads) {   // (eight gathers in flight per thread)
-            double v[8];
-            int at[8];
+        // stage rows 0 .. hi of the block's columns: a thread per row, all columns' loads in flight at once (rows below
+        // a column's pivot are loaded too and never used)
+        if (t < hi) {
+            double v[kBlkTriCols];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * kBlkThreads;
-                const int c = e < ne ? e / hi : 0, r = e < ne ? e - c * hi : 0;
-                at[u] = c * m + r;
-                v[u] = a[(size_t)r * n + index[lo + c]];
-            }
+            for (int c = 0; c < kBlkTriCols; ++c) v[c] = c < nc ? Rs[(size_t)slotpos[lo + c] * m + t] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u * kBlkThreads < ne) tri[at[u]] = v[u];
+            for (int c = 0; c < kBlkTriCols; ++c)
+                if (c < nc) tri[c * m + t] = v[c];
         }
         __syncthreads();
-        // The diagonal block in ONE wavefront, a lane per row: its nc dependent steps then cost a cross-lane read, a
-        // multiplication and an FMA each -- no barrier, and the division is taken out of the chain (reciprocals of the
-        // nc pivots at once: z * (1 / d) instead of z / d, within an ulp of it).
+        // The diagonal block in ONE wavefront, a lane per row: its nc dependent steps then cost two cross-lane reads, a
+        // multiplication and an FMA each -- no barrier, the block's entries in registers, and the division taken out
+        // of the chain (reciprocals of the nc pivots at once: z * (1 / d) instead of z / d, within an ulp of it).
         if (t < 64) {
-            const int row = lo + t;
+            const int row = lo + (t < nc ? t : 0);
             double z = t < nc ? zz[row] : 0.0;
             const double rd = t < nc ? 1.0 / tri[t * m + row] : 0.0;
-            for (int c = nc - 1; c >= 0; --c) {
-                const double zi = lane_f64(z, c) * lane_f64(rd, c);
-                if (t == c) z = zi;
-                if (t < c) z = fma(-tri[c * m + row], zi, z);
+            double tc[kBlkTriCols];
+#pragma unroll
+            for (int c = 0; c < kBlkTriCols; ++c) tc[c] = c < nc ? tri[c * m + row] : 0.0;
+#pragma unroll
+            for (int c = kBlkTriCols - 1; c >= 0; --c) {
+                if (c < nc) {
+                    const double zi = lane_f64(z, c) * lane_f64(rd, c);
+                    if (t == c) z = zi;
+                    if (t < c) z = fma(-tc[c], zi, z);
+                }
             }
             if (t < nc) zz[row] = z;
         }
@@ -210,16 +228,17 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
     const int t = threadIdx.x, m = P.rows, n = P.cols;
     const long long k = blockIdx.x;
     double *bs = lds, *zz = bs + m, *uu = zz + m, *xs = uu + m, *ws = xs + n, *slots = ws + n;
-    double *gslot = slots + 8;            // 2 x 4 doubles: (c, s, sig) of the rotation in flight
-    double *tri = slots + 16;
-    int *index = reinterpret_cast<int *>(tri + (size_t)kBlkTriCols * m), *pos = index + n;
+    double *rotc = slots + 8, *rots = rotc + m;   // rotations of a deletion, by the row they end in
+    double *tri = rots + m;
+    int *index = reinterpret_cast<int *>(tri + (size_t)kBlkTriCols * m), *pos = index + n, *slotpos = pos + n;
     BlockReduce red{slots, 0};
 
     double *a = P.work + k * (long long)m * n;
+    double *Rs = P.factor + k * (long long)m * m;
     const double *A = P.A + k * P.a_stride;
     const int skip = P.skip_rows ? P.skip_rows[k] : 0;
     for (size_t e = t; e < (size_t)m * n; e += kBlkThreads) a[e] = (int)(e / n) >= skip ? A[e] : 0.0;
-    if (t < m) bs[t] = t >= skip ? P.b[k * P.b_stride + t] : 0.0;
+    if (t < m) { bs[t] = t >= skip ? P.b[k * P.b_stride + t] : 0.0; slotpos[t] = t; }
     for (int j = t; j < n; j += kBlkThreads) { xs[j] = 0.0; ws[j] = 0.0; index[j] = j; pos[j] = j; }
     __syncthreads();
 
@@ -310,12 +329,13 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
                     }
                 }
             }
-            if (t == piv) a[(size_t)t * n + j] = newpiv;
-            if (t > piv && t < m) a[(size_t)t * n + j] = 0.0;
+            // its column of the factor goes to the first free slot (its entries in the matrix are stale from here on:
+            // nothing reads a column of P there, and a column that leaves P is written back first)
+            if (t <= piv) Rs[(size_t)slotpos[piv] * m + t] = t < piv ? cj : newpiv;
         }
         __syncthreads();
         BLK_TICK(2)
-        blk_trisolve(a, n, m, nsetp, index, zz, tri);   // zz == bs here
+        blk_trisolve(Rs, m, nsetp, slotpos, zz, tri);   // zz == bs here
         BLK_TICK(3)
         // secondary loop
         for (;;) {
@@ -337,35 +357,88 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
             __syncthreads();
             int i = index[jj];
             for (;;) {
-                // column i leaves P: the columns behind it move up one position, a rotation each
+                // Column i (position jj) leaves P: the columns behind it move up one position, a rotation each.
+                const int np = nsetp, q = jj + 1 + t;          // this thread's column of the factor, if q < np
+                const bool mine = q < np;
+                const int sl_del = slotpos[jj];
+                const int my_sl = mine ? slotpos[q] : 0, my_col = mine ? index[q] : 0;
+                // it returns to Z with its entries as they stand now: rows 0 .. jj from its slot, zeros below
+                if (t < m) a[(size_t)t * n + i] = t <= jj ? Rs[(size_t)sl_del * m + t] : 0.0;
                 if (t == 0) xs[i] = 0.0;
-                for (int jc = jj + 1; jc < nsetp; ++jc) {
-                    const int ii = index[jc];
-                    double *gs = gslot + (jc & 1) * 4;
-                    if (t == (ii & (kBlkThreads - 1))) {
-                        double cc, ss, sig;
-                        blk_givens(a[(size_t)(jc - 1) * n + ii], a[(size_t)jc * n + ii], cc, ss, sig);
-                        gs[0] = cc; gs[1] = ss; gs[2] = sig;
-                    }
-                    __syncthreads();
-                    const double cc = gs[0], ss = gs[1], sig = gs[2];
-                    double *r0 = a + (size_t)(jc - 1) * n, *r1 = a + (size_t)jc * n;
-                    for (int c = t; c < n; c += kBlkThreads) {
-                        if (c == ii) { r0[c] = sig; r1[c] = 0.0; continue; }
-                        const double v0 = r0[c], v1 = r1[c];
-                        r0[c] = fma(cc, v0, ss * v1);
-                        r1[c] = fma(-ss, v0, cc * v1);
-                    }
-                    if (t == 0) {
-                        index[jc - 1] = ii; pos[ii] = jc - 1;
-                        const double v0 = bs[jc - 1], v1 = bs[jc];
-                        bs[jc - 1] = fma(cc, v0, ss * v1);
-                        bs[jc] = fma(-ss, v0, cc * v1);
+                // Rotations, generated on the factor: rotation s acts on rows s - 1 and s and is fixed by the column at
+                // position s, after the rotations before it.  A thread per column, eight rows loaded and stored at a time;
+                // the dependent chain runs through rotc / rots in LDS, one barrier per rotation.
+                {
+                    double *base = Rs + (size_t)my_sl * m;
+                    double carry = mine ? base[jj] : 0.0;
+                    for (int s0 = jj + 1; s0 < np; s0 += 8) {
+                        double v[8], out[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            v[u] = (mine && s0 + u <= q) ? base[s0 + u] : 0.0;
+                            out[u] = 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int s = s0 + u;
+                            if (s < np) {
+                                if (mine && q == s) {
+                                    double cc, ss, sig;
+                                    blk_givens_fast(carry, v[u], cc, ss, sig);
+                                    rotc[s] = cc; rots[s] = ss; out[u] = sig;
+                                }
+                                __syncthreads();
+                                if (mine && q > s) {
+                                    const double cc = rotc[s], ss = rots[s];
+                                    out[u] = fma(cc, carry, ss * v[u]);
+                                    carry = fma(-ss, carry, cc * v[u]);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (mine && s0 + u <= q) base[s0 + u - 1] = out[u];
                     }
                 }
-                --nsetp;
+                __syncthreads();   // (the column written back above is visible to its owner below even without a rotation)
+                // ... applied to every column outside P, the leaving one included, and to the right-hand side (c == n):
+                // a thread per column down the rows jj .. np - 1, no barrier
+                if (np - 1 > jj)
+                    for (int c = t; c <= n; c += kBlkThreads) {
+                        if (c == n) {
+                            double v0 = bs[jj];
+                            for (int s = jj + 1; s < np; ++s) {
+                                const double v1 = bs[s];
+                                bs[s - 1] = fma(rotc[s], v0, rots[s] * v1);
+                                v0 = fma(-rots[s], v0, rotc[s] * v1);
+                            }
+                            bs[np - 1] = v0;
+                            continue;
+                        }
+                        if (pos[c] < np && c != i) continue;
+                        double v0 = a[(size_t)jj * n + c];
+                        int s = jj + 1;
+                        for (; s + kBlkUnroll <= np; s += kBlkUnroll) {
+                            double v[kBlkUnroll];
+#pragma unroll
+                            for (int u = 0; u < kBlkUnroll; ++u) v[u] = a[(size_t)(s + u) * n + c];
+#pragma unroll
+                            for (int u = 0; u < kBlkUnroll; ++u) {
+                                a[(size_t)(s + u - 1) * n + c] = fma(rotc[s + u], v0, rots[s + u] * v[u]);
+                                v0 = fma(-rots[s + u], v0, rotc[s + u] * v[u]);
+                            }
+                        }
+                        for (; s < np; ++s) {
+                            const double v1 = a[(size_t)s * n + c];
+                            a[(size_t)(s - 1) * n + c] = fma(rotc[s], v0, rots[s] * v1);
+                            v0 = fma(-rots[s], v0, rotc[s] * v1);
+                        }
+                        a[(size_t)(np - 1) * n + c] = v0;
+                    }
                 __syncthreads();
-                if (t == 0) { index[nsetp] = i; pos[i] = nsetp; }
+                if (mine) { index[q - 1] = my_col; pos[my_col] = q - 1; slotpos[q - 1] = my_sl; }
+                if (t == 0) { index[np - 1] = i; pos[i] = np - 1; slotpos[np - 1] = sl_del; }
+                --nsetp;
                 __syncthreads();
                 // round-off guard: whatever is left in P with a non-positive coefficient leaves too
                 jj = red.min_int(t < nsetp && xs[index[t]] <= 0.0 ? t : 0x7fffffff);
@@ -375,7 +448,7 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
             if (t < m) zz[t] = bs[t];
             __syncthreads();
             BLK_TICK(4)
-            blk_trisolve(a, n, m, nsetp, index, zz, tri);
+            blk_trisolve(Rs, m, nsetp, slotpos, zz, tri);
             BLK_TICK(3)
         }
         if (mode != 0) break;

@@ -545,7 +545,7 @@ size_t pympc_nnls_workspace_doubles(int rows, int cols, int64_t B)
 {
     const int R = rows < 2 ? 2 : rows;
     if (rows < 1 || cols < 1 || rows > kBlkRowsMax || cols > kMMax || B < 0) return 0;
-    if (R - 1 > kNMax) return (size_t)rows * cols * (size_t)B + 32;   // nnls_block_kernel: a working copy of each matrix
+    if (R - 1 > kNMax) return ((size_t)rows * cols + (size_t)rows * rows) * (size_t)B + 32;   // nnls_block_kernel: a working copy of each matrix and its triangular factor
     return (ws_layout(R - 1, cols, 0).total + (size_t)R) * (size_t)B + 32;
 }
 
@@ -559,7 +559,7 @@ int launch_nnls_block(int rows, int cols, int64_t B, const double *A, int64_t a_
     Q.rows = rows; Q.cols = cols;
     Q.itmax = (int)std::min<long long>(g_tune.nnls_itmax_factor.load() * (long long)cols, 0x7fffffffLL);
     Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = b_stride; Q.skip_rows = skip_rows;
-    Q.work = work; Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
+    Q.work = work; Q.factor = work + (size_t)rows * cols * (size_t)B; Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
     const size_t lds = nnls_block_lds_bytes(rows, cols);
     if (int rc = allow_lds(nnls_block_kernel, lds)) return rc;
     hipLaunchKernelGGL(nnls_block_kernel, dim3((unsigned)B), dim3(kBlkThreads), lds, st, Q);
@@ -660,7 +660,7 @@ size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)
 {
     if (n < 1 || m < 1 || n > kQpBlockNMax || m > kMMax || B < 0) return 0;
     if (n > kNMax) {   // qp_block.hpp: factors and NNLS matrix per problem, the NNLS kernel's working copy, y, scalars
-        const size_t per = qp_block_layout(n, m).total + (size_t)(n + 1) * m + (size_t)m + 4;
+        const size_t per = qp_block_layout(n, m).total + (size_t)(n + 1) * m + (size_t)(n + 1) * (n + 1) + (size_t)m + 4;
         return per * (size_t)B + (size_t)n + 2 + 32;
     }
     // per-problem prepared workspace + one int32 prepare status per problem (stored after the workspaces)
@@ -679,7 +679,7 @@ int qp_block_solve(int n, int m, int64_t B, const double *H, int64_t h_stride, c
     P.n = n; P.m = m; P.H = H; P.h_stride = h_stride; P.f = f; P.A = A; P.a_stride = a_stride; P.b = b; P.tol = tol;
     P.ws = ws;
     double *work = ws + L.total * (size_t)B;               // [B x (n + 1) x m]
-    P.y = work + (size_t)(n + 1) * m * (size_t)B;          // [B x m]
+    P.y = work + ((size_t)(n + 1) * m + (size_t)(n + 1) * (n + 1)) * (size_t)B;   // [B x m] (behind the NNLS kernel's matrices and factors)
     P.rn = P.y + (size_t)m * (size_t)B;                    // [B]
     P.bn = P.rn + (size_t)B;                               // [n + 1] (+ 1 pad)
     P.nnls_status = reinterpret_cast<int32_t *>(P.bn + (((size_t)n + 2) & ~(size_t)1));   // [B], then iters [2B], notpd [B]

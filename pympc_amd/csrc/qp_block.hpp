@@ -87,9 +87,17 @@ __global__ void __launch_bounds__(kBlkThreads) qp_block_prepare_kernel(QpBlockPa
         if (t == j) L[(size_t)j * n + j] = s;
         if (t > j && t < n) L[(size_t)t * n + j] = L[(size_t)t * n + j] / s;
         __syncthreads();
-        if (t > j && t < n) {
+        if (t > j && t < n) {   // (eight rows' loads in flight: one workgroup per problem, nothing else hides the latency)
             const double lcj = L[(size_t)t * n + j];
-            for (int i = t; i < n; ++i) L[(size_t)i * n + t] = fma(-L[(size_t)i * n + j], lcj, L[(size_t)i * n + t]);
+            int i = t;
+            for (; i + 8 <= n; i += 8) {
+                double lj[8], lt[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { lj[u] = L[(size_t)(i + u) * n + j]; lt[u] = L[(size_t)(i + u) * n + t]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) L[(size_t)(i + u) * n + t] = fma(-lj[u], lcj, lt[u]);
+            }
+            for (; i < n; ++i) L[(size_t)i * n + t] = fma(-L[(size_t)i * n + j], lcj, L[(size_t)i * n + t]);
         }
         __syncthreads();
     }
@@ -104,7 +112,15 @@ __global__ void __launch_bounds__(kBlkThreads) qp_block_prepare_kernel(QpBlockPa
             double s = 0.0;
             if (i >= t) {
                 s = i == t ? 1.0 : 0.0;
-                for (int q = t; q < i; ++q) s = fma(-L[(size_t)i * n + q], Li[(size_t)q * n + t], s);
+                int q = t;
+                for (; q + 8 <= i; q += 8) {
+                    double lv[8], zv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { lv[u] = L[(size_t)i * n + q + u]; zv[u] = Li[(size_t)(q + u) * n + t]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fma(-lv[u], zv[u], s);
+                }
+                for (; q < i; ++q) s = fma(-L[(size_t)i * n + q], Li[(size_t)q * n + t], s);
                 s = s / L[(size_t)i * n + i];
             }
             Li[(size_t)i * n + t] = s;
@@ -128,10 +144,20 @@ __global__ void __launch_bounds__(kBlkThreads) qp_block_prepare_kernel(QpBlockPa
     __syncthreads();
     // the NNLS matrix, a constraint row per thread
     for (int r = t; r < m; r += kBlkThreads) {
-        for (int c = 0; c < n; ++c) {
-            double s = 0.0;
-            for (int q = 0; q <= c; ++q) s = fma(At[(size_t)q * m + r], Li[(size_t)c * n + q], s);
-            An[(size_t)c * m + r] = -s;
+        // eight columns of M at a time: one pass over the row of A for eight sums (the entries of L^-1 above its
+        // diagonal are stored zeros, which add nothing: the sums are those of the loop q <= c)
+        for (int c0 = 0; c0 < n; c0 += 8) {
+            double sv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const int cl = c0 + 8 <= n ? c0 + 7 : n - 1;
+            for (int q = 0; q <= cl; ++q) {
+                const double av = At[(size_t)q * m + r];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + u < n) sv[u] = fma(av, Li[(size_t)(c0 + u) * n + q], sv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < n) An[(size_t)(c0 + u) * m + r] = -sv[u];
         }
         double s = 0.0;
         for (int q = 0; q < n; ++q) s = fma(At[(size_t)q * m + r], hs[q], s);

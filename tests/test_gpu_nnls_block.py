@@ -160,3 +160,9 @@ def test_lp_in_the_reference_form_beyond_64_rows(oracle):
             ref = oracle.linear_program(f, A2, b2); sol = linear_program_pnnls(f, A2, b2)
             assert (sol['min'] is None) == (ref['min'] is None), (n, m, gap)
     assert n_solv >= 4
+    # the same through the dispatch of optimization/programs.py
+    from pympc_amd.optimization.programs import linear_program
+    sol = linear_program(f, A, b, solver='hip_kkt'); ref = oracle.linear_program(f, A, b)
+    assert abs(sol['min'] - ref['min']) < 1e-7 and sol['active_set'] == ref['active_set']
+    with pytest.raises(ValueError, match='unknown solver'):
+        linear_program(f, A, b, solver='gurobi')

@@ -152,17 +152,29 @@ __device__ __forceinline__ double blk_col_dot(const double *a, int n, int j, int
     for (; l < m; ++l) sm = fma(a[(size_t)l * n + j], vec[l], sm);
     return sm;
 }
-__device__ __forceinline__ void blk_col_axpy(double *a, int n, int j, int l0, int m, const double *vec, double sm)
+// a[l][j] += sm vec[l] for l0 <= l < m; returns the dot product of the NEW entries with `rhs` (the next dual-vector entry
+// of this column, summed in the order blk_col_dot would use: one pass over the matrix less per entering column)
+__device__ __forceinline__ double blk_col_axpy_dot(double *a, int n, int j, int l0, int m, const double *vec, double sm, const double *rhs)
 {
+    double w = 0.0;
     int l = l0;
     for (; l + kBlkUnroll <= m; l += kBlkUnroll) {
         double v[kBlkUnroll];
 #pragma unroll
         for (int u = 0; u < kBlkUnroll; ++u) v[u] = a[(size_t)(l + u) * n + j];
 #pragma unroll
-        for (int u = 0; u < kBlkUnroll; ++u) a[(size_t)(l + u) * n + j] = fma(sm, vec[l + u], v[u]);
+        for (int u = 0; u < kBlkUnroll; ++u) {
+            v[u] = fma(sm, vec[l + u], v[u]);
+            a[(size_t)(l + u) * n + j] = v[u];
+            w = fma(v[u], rhs[l + u], w);
+        }
     }
-    for (; l < m; ++l) a[(size_t)l * n + j] = fma(sm, vec[l], a[(size_t)l * n + j]);
+    for (; l < m; ++l) {
+        const double v = fma(sm, vec[l], a[(size_t)l * n + j]);
+        a[(size_t)l * n + j] = v;
+        w = fma(v, rhs[l], w);
+    }
+    return w;
 }
 
 // zz[0 .. nsetp) <- solution of the triangular system whose column at position ip sits in slot slotpos[ip] of the
@@ -244,14 +256,18 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
 
     const double factor = 0.01;
     int iter = 0, outer = 0, mode = 0, nsetp = 0;   // P = index[0 .. nsetp), Z = index[nsetp .. n)
+    bool dual_ready = false;                        // ws already holds the dual vector (from the Householder pass below)
     for (;;) {
         if (nsetp >= n || nsetp >= m) break;
         // dual vector on Z
-        for (int j = t; j < n; j += kBlkThreads) {
-            if (pos[j] < nsetp) continue;
-            ws[j] = blk_col_dot(a, n, j, nsetp, m, bs, 0.0);
+        if (!dual_ready) {
+            for (int j = t; j < n; j += kBlkThreads) {
+                if (pos[j] < nsetp) continue;
+                ws[j] = blk_col_dot(a, n, j, nsetp, m, bs, 0.0);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        dual_ready = false;
         BLK_TICK(0)
         bool accepted = false;
         int j = -1, izmax = -1;
@@ -322,12 +338,16 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
                     if (pos[c] < nsetp) continue;
                     const double ap = a[(size_t)piv * n + c];
                     double sm = blk_col_dot(a, n, c, piv + 1, m, uu, ap * up);
+                    // (bs is the new right-hand side already and rows piv + 1 .. are the rows the next dual vector sums)
                     if (sm != 0.0) {
                         sm *= binv;
                         a[(size_t)piv * n + c] = fma(sm, up, ap);
-                        blk_col_axpy(a, n, c, piv + 1, m, uu, sm);
+                        ws[c] = blk_col_axpy_dot(a, n, c, piv + 1, m, uu, sm, bs);
+                    } else {
+                        ws[c] = blk_col_dot(a, n, c, piv + 1, m, bs, 0.0);
                     }
                 }
+                dual_ready = true;
             }
             // its column of the factor goes to the first free slot (its entries in the matrix are stale from here on:
             // nothing reads a column of P there, and a column that leaves P is written back first)
@@ -358,6 +378,7 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
             int i = index[jj];
             for (;;) {
                 // Column i (position jj) leaves P: the columns behind it move up one position, a rotation each.
+                dual_ready = false;
                 const int np = nsetp, q = jj + 1 + t;          // this thread's column of the factor, if q < np
                 const bool mine = q < np;
                 const int sl_del = slotpos[jj];

@@ -127,3 +127,36 @@ def test_mpqp_with_many_variables_is_solved_state_by_state(oracle):
     assert res.numpy("argmin").shape == (24, 3) and np.isnan(res.numpy("min")[~ok]).all()
     lam = ref["multiplier_inequality"][ok]
     assert np.allclose(res.numpy("multiplier_inequality")[ok], lam, rtol=0, atol=1e-6 * max(1.0, np.abs(lam).max()))
+
+
+def test_linear_mpc_with_horizon_70_end_to_end(oracle):
+    """ModelPredictiveController on the double integrator with N = 70 (70 optimisation variables: refused until the
+    workgroup-per-problem QP path existed): condensing kernel -> mpQP without prepared form -> feedforward / feedback
+    over a batch of states, against the oracle's per-state loop on the same condensed problem."""
+    from pympc_amd.control.controllers import ModelPredictiveController
+    from pympc_amd.dynamics.discrete_time_systems import LinearSystem
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    A = np.array([[1., 1.], [0., 1.]]); B = np.array([[.5], [1.]])
+    S = LinearSystem(A, B)
+    X = Polyhedron.from_bounds(np.array([-8., -2.]), np.array([8., 2.]))
+    U = Polyhedron.from_bounds(np.array([-1.]), np.array([1.]))
+    D = X.cartesian_product(U)
+    Q, R = np.eye(2), np.eye(1)
+    P, K = S.solve_dare(Q, R)
+    X_N = S.mcais(K, D)
+    ctrl = ModelPredictiveController(S, 70, Q, R, P, D, X_N)
+    mp = ctrl.mpqp
+    assert mp.A['u'].shape[1] == 70 and mp.prepared().large
+    rng = np.random.RandomState(5)
+    xs = rng.uniform(-1., 1., (12, 2)) * np.array([7., 1.8])
+    model = dict(Huu=mp.H['uu'], Hux=mp.H['ux'], Hxx=mp.H['xx'], fu=mp.f['u'], fx=mp.f['x'], g=mp.g, Au=mp.A['u'], Ax=mp.A['x'], b=mp.b)
+    ref = oracle.mpqp_solve_batch(model, xs)
+    Ub, Vb, okb = ctrl.feedforward(xs)
+    ok = ref["status"] == 0
+    assert np.array_equal(np.asarray(okb, bool), ok) and 0 < ok.sum()
+    assert np.allclose(np.asarray(Vb)[ok], ref["min"][ok], rtol=1e-7, atol=1e-7)
+    assert np.allclose(np.asarray(Ub)[ok].reshape(int(ok.sum()), -1), ref["argmin"][ok], rtol=0, atol=1e-6)
+    # one state through the scalar API
+    k = int(np.where(ok)[0][0])
+    u_seq, V = ctrl.feedforward(xs[k])
+    assert abs(V - ref["min"][k]) < 1e-7 * max(1.0, abs(ref["min"][k])) and abs(ctrl.feedback(xs[k])[0] - ref["argmin"][k, 0]) < 1e-6

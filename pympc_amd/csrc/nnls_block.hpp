@@ -11,7 +11,7 @@
 //   * vectors over rows (right-hand side, trial solution, reflector) and over columns (x, w, the index permutation and
 //     its inverse) live in LDS; scalars every thread needs come from block reductions of one barrier each;
 //   * the columns of the matrix that are in the set P have a second home: a packed, column-contiguous copy of the
-//     triangular factor in device memory (a slot per column).  The triangular solves stage 32 of its columns in LDS at
+//     triangular factor in device memory (a slot per column).  The triangular solves stage 16 of its columns in LDS at
 //     a time (coalesced) and run the reference's column-oriented back substitution on them; when a column leaves P the
 //     rotations are generated on that copy (a thread per column, the chain of dependent rotations through LDS) and then
 //     applied to all other columns of the matrix in one pass without barriers;
@@ -31,7 +31,13 @@ namespace pympc {
 constexpr int kBlkThreads = 256;
 constexpr int kBlkWaves = kBlkThreads / 64;
 constexpr int kBlkRowsMax = 256;   // one row per thread
-constexpr int kBlkTriCols = 32;    // columns of the triangular factor staged in LDS at a time
+#ifndef PYMPC_BLK_TRI_COLS
+#define PYMPC_BLK_TRI_COLS 16
+#endif
+// Columns of the triangular factor staged in LDS at a time.  One problem alone runs the same with 8, 16 or 32 (the solve
+// is a latency chain either way); a batch gains from the smaller footprint (256 x 500: 56 instead of 84 KB of LDS, two
+// workgroups per CU instead of one: 512 problems 79 -> 68 ms).
+constexpr int kBlkTriCols = PYMPC_BLK_TRI_COLS;
 
 struct NnlsBlockParams {
     int rows, cols;

@@ -1,4 +1,4 @@
-// NNLS and the PNNLS reduction for problems of 65 .. 256 rows: one workgroup of 256 threads per problem.
+// NNLS and the PNNLS reduction for problems of 65 .. 512 rows: one workgroup of 256 (up to 256 rows) or 512 threads per problem.
 //
 // The wave kernel of qp_wave.hpp keeps one row per lane, which ends at 64 rows (QPs of up to 63 variables, LPs in the
 // reference's KKT form of pnnls.py:109-124 with 1 + m + n <= 64).  The reference has no such limit
@@ -28,9 +28,11 @@
 
 namespace pympc {
 
-constexpr int kBlkThreads = 256;
-constexpr int kBlkWaves = kBlkThreads / 64;
-constexpr int kBlkRowsMax = 256;   // one row per thread
+// One row per thread: 256 threads up to 256 rows, 512 threads (two wavefronts per SIMD, 256 VGPRs each) up to 512.
+constexpr int kBlkThreadsSmall = 256;
+constexpr int kBlkThreadsBig = 512;
+constexpr int kBlkRowsMax = kBlkThreadsBig;
+__host__ __device__ inline int blk_threads(int rows) { return rows <= kBlkThreadsSmall ? kBlkThreadsSmall : kBlkThreadsBig; }
 #ifndef PYMPC_BLK_TRI_COLS
 #define PYMPC_BLK_TRI_COLS 16
 #endif
@@ -57,22 +59,36 @@ struct NnlsBlockParams {
 
 __host__ __device__ inline size_t nnls_block_lds_bytes(int rows, int cols)
 {
-    // doubles: b, zz, u [rows] | x, w [cols] | reduction slots [8] | rotations c, s [rows] | staged factor [kBlkTriCols x rows]
+    // doubles: b, zz, u [rows] | x, w [cols] | reduction slots [16] | rotations c, s [rows] | staged factor [kBlkTriCols x rows]
     // ints: index, pos [cols], slotpos [rows]
-    return ((size_t)(5 + kBlkTriCols) * rows + (size_t)2 * cols + 8) * 8 + (((size_t)2 * cols + rows) * 4 + 7) / 8 * 8;
+    return ((size_t)(5 + kBlkTriCols) * rows + (size_t)2 * cols + 16) * 8 + (((size_t)2 * cols + rows) * 4 + 7) / 8 * 8;
 }
 
 // Block reductions over 256 threads through alternating LDS slots: reduction k writes slot k & 1, so a writer of
 // reduction k + 2 has passed the barrier of k + 1 and with it every read of reduction k -- one barrier each.
 // Every thread must take part in every reduction, in the same order.
+template <int W>
 struct BlockReduce {
-    double *slot;   // 2 x kBlkWaves doubles
+    double *slot;   // 2 x W doubles (W wavefronts)
     int phase;
     __device__ __forceinline__ double *next()
     {
-        double *s = slot + (phase & 1) * kBlkWaves;
+        double *s = slot + (phase & 1) * W;
         ++phase;
         return s;
+    }
+    // pairwise over the wavefronts' values: ((s0 + s1) + (s2 + s3)) + ...
+    template <typename F>
+    __device__ __forceinline__ static double tree(const double *s, F f)
+    {
+        double v[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) v[i] = s[i];
+#pragma unroll
+        for (int stride = 1; stride < W; stride *= 2)
+#pragma unroll
+            for (int i = 0; i + stride < W; i += 2 * stride) v[i] = f(v[i], v[i + stride]);
+        return v[0];
     }
     __device__ __forceinline__ double sum(double v)
     {
@@ -80,7 +96,7 @@ struct BlockReduce {
         double *s = next();
         if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
         __syncthreads();
-        return (s[0] + s[1]) + (s[2] + s[3]);
+        return tree(s, [](double a, double b) { return a + b; });
     }
     __device__ __forceinline__ double max(double v)
     {
@@ -88,7 +104,7 @@ struct BlockReduce {
         double *s = next();
         if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
         __syncthreads();
-        return max_raw(max_raw(s[0], s[1]), max_raw(s[2], s[3]));
+        return tree(s, [](double a, double b) { return max_raw(a, b); });
     }
     __device__ __forceinline__ double min(double v)
     {
@@ -96,7 +112,7 @@ struct BlockReduce {
         double *s = next();
         if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
         __syncthreads();
-        return min_raw(min_raw(s[0], s[1]), min_raw(s[2], s[3]));
+        return tree(s, [](double a, double b) { return min_raw(a, b); });
     }
     __device__ __forceinline__ int min_int(int v)
     {
@@ -104,7 +120,10 @@ struct BlockReduce {
         int *s = reinterpret_cast<int *>(next());
         if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
         __syncthreads();
-        return ::min(::min(s[0], s[1]), ::min(s[2], s[3]));
+        int r = s[0];
+#pragma unroll
+        for (int i = 1; i < W; ++i) r = ::min(r, s[i]);
+        return r;
     }
 };
 
@@ -237,8 +256,10 @@ __device__ __forceinline__ void blk_trisolve(const double *Rs, int m, int nsetp,
 #else
 #define BLK_TICK(slot)
 #endif
-__global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams P)
+template <int T>
+__global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
 {
+    constexpr int kBlkThreads = T;
 #ifdef PYMPC_BLK_PROFILE
     long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = wall_clock64();
 #endif
@@ -246,10 +267,10 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
     const int t = threadIdx.x, m = P.rows, n = P.cols;
     const long long k = blockIdx.x;
     double *bs = lds, *zz = bs + m, *uu = zz + m, *xs = uu + m, *ws = xs + n, *slots = ws + n;
-    double *rotc = slots + 8, *rots = rotc + m;   // rotations of a deletion, by the row they end in
+    double *rotc = slots + 16, *rots = rotc + m;   // rotations of a deletion, by the row they end in
     double *tri = rots + m;
     int *index = reinterpret_cast<int *>(tri + (size_t)kBlkTriCols * m), *pos = index + n, *slotpos = pos + n;
-    BlockReduce red{slots, 0};
+    BlockReduce<T / 64> red{slots, 0};
 
     double *a = P.work + k * (long long)m * n;
     double *Rs = P.factor + k * (long long)m * m;
@@ -496,22 +517,24 @@ __global__ void __launch_bounds__(kBlkThreads) nnls_block_kernel(NnlsBlockParams
     }
 }
 
-// ---------------------------------------------------------------------------------------- PNNLS, 65 .. 256 rows
+// ---------------------------------------------------------------------------------------- PNNLS, 65 .. 512 rows
 // pnnls_reduce_kernel of nnls_raw.hpp with one row per thread: Householder QR of B with column pivoting applied to
 // [A | c].  LDS: B (rows x (nu | 1)), the reflector, reduction slots, the permutation.
 __host__ __device__ inline size_t pnnls_block_lds_bytes(int rows, int nu)
 {
-    return ((size_t)rows * (nu | 1) + rows + 8) * 8 + (size_t)(nu + 1) * 4;
+    return ((size_t)rows * (nu | 1) + rows + 16) * 8 + (size_t)(nu + 1) * 4;
 }
 
-__global__ void __launch_bounds__(kBlkThreads) pnnls_reduce_block_kernel(PnnlsParams P)
+template <int T>
+__global__ void __launch_bounds__(T) pnnls_reduce_block_kernel(PnnlsParams P)
 {
+    constexpr int kBlkThreads = T;
     extern __shared__ double lds[];
     const long long k = blockIdx.x;
     const int rows = P.rows, cols = P.cols, nu = P.nu, ld = nu | 1, t = threadIdx.x;
     double *Bs = lds, *vv = Bs + (size_t)rows * ld, *slots = vv + rows;
-    int *perm = reinterpret_cast<int *>(slots + 8);
-    BlockReduce red{slots, 0};
+    int *perm = reinterpret_cast<int *>(slots + 16);
+    BlockReduce<T / 64> red{slots, 0};
     const double *A = P.A + k * (long long)rows * cols;
     double *QA = P.QA + k * (long long)rows * cols;
     double *Qc = P.Qc + k * (long long)rows;

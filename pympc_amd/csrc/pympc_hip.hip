@@ -561,8 +561,13 @@ int launch_nnls_block(int rows, int cols, int64_t B, const double *A, int64_t a_
     Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = b_stride; Q.skip_rows = skip_rows;
     Q.work = work; Q.factor = work + (size_t)rows * cols * (size_t)B; Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
     const size_t lds = nnls_block_lds_bytes(rows, cols);
-    if (int rc = allow_lds(nnls_block_kernel, lds)) return rc;
-    hipLaunchKernelGGL(nnls_block_kernel, dim3((unsigned)B), dim3(kBlkThreads), lds, st, Q);
+    if (blk_threads(rows) == kBlkThreadsSmall) {
+        if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsSmall>, lds)) return rc;
+        hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), lds, st, Q);
+    } else {
+        if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsBig>, lds)) return rc;
+        hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), lds, st, Q);
+    }
     return check_launch("nnls_block_kernel");
 }
 }  // namespace
@@ -597,6 +602,7 @@ int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_s
 size_t pympc_pnnls_workspace_doubles(int rows, int cols, int nu, int64_t B)
 {
     if (rows < 1 || rows > kBlkRowsMax || cols < 1 || cols > kMMax || nu < 0 || nu > 64 || B < 0) return 0;
+    if (rows > 64 && pnnls_block_lds_bytes(rows, nu) > kLdsBytes) return 0;   // the reduction keeps B (rows x nu) in LDS
     const size_t nn = pympc_nnls_workspace_doubles(rows, cols, B);
     if (nn == 0) return 0;
     return nn + ((size_t)rows * cols + rows + (size_t)rows * nu + nu + 2) * (size_t)B + 32;
@@ -606,9 +612,9 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
                       double *v, double *u, double *rnorm, int32_t *status, int32_t *iters, void *stream)
 {
     if (rows < 1 || cols < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: bad shape");
-    if (rows > kBlkRowsMax || nu > 64 || cols > kMMax)
-        return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of %d rows, 64 free and %d sign-constrained variables",
-                    rows, cols, nu, kBlkRowsMax, kMMax);
+    if (rows > kBlkRowsMax || nu > 64 || cols > kMMax || (rows > 64 && pnnls_block_lds_bytes(rows, nu) > kLdsBytes))
+        return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of %d rows, 64 free and %d sign-constrained variables "
+                    "(and rows x free variables within 160 KiB of LDS)", rows, cols, nu, kBlkRowsMax, kMMax);
     if (B == 0) return 0;
     if (!A || !c || !ws || !v || !status || (nu > 0 && (!Bm || !u))) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: null pointer");
     if (nu == 0) return pympc_nnls_batch(rows, cols, B, A, (int64_t)rows * cols, c, ws, v, rnorm, status, iters, stream);
@@ -626,8 +632,13 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
     hipStream_t st = (hipStream_t)stream;
     if (rows > 64) {   // one row per thread of a workgroup instead of one per lane (nnls_block.hpp)
         const size_t ldsb = pnnls_block_lds_bytes(rows, nu);
-        if (int rc = allow_lds(pnnls_reduce_block_kernel, ldsb)) return rc;
-        hipLaunchKernelGGL(pnnls_reduce_block_kernel, dim3((unsigned)B), dim3(kBlkThreads), ldsb, st, R);
+        if (blk_threads(rows) == kBlkThreadsSmall) {
+            if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsSmall>, ldsb)) return rc;
+            hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), ldsb, st, R);
+        } else {
+            if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsBig>, ldsb)) return rc;
+            hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), ldsb, st, R);
+        }
         if (int rc = check_launch("pnnls_reduce_block_kernel")) return rc;
         if (int rc = launch_nnls_block(rows, cols, B, R.QA, (int64_t)rows * cols, R.Qc, rows, R.rank, ws, v, rnorm, status, iters, st)) return rc;
         hipLaunchKernelGGL(pnnls_recover_kernel, dim3((unsigned)B), dim3(64), (64 + 64 * 65 + 64) * 8, st, R);
@@ -686,12 +697,15 @@ int qp_block_solve(int n, int m, int64_t B, const double *H, int64_t h_stride, c
     P.nnls_iters = P.nnls_status + (size_t)B;
     P.notpd = P.nnls_iters + 2 * (size_t)B;
     P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
-    hipLaunchKernelGGL(qp_block_prepare_kernel, dim3((unsigned)B), dim3(kBlkThreads), 0, st, P);
+    const bool small = blk_threads(n + 1) == kBlkThreadsSmall;
+    if (small) hipLaunchKernelGGL(qp_block_prepare_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), 0, st, P);
+    else hipLaunchKernelGGL(qp_block_prepare_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), 0, st, P);
     if (int rc = check_launch("qp_block_prepare_kernel")) return rc;
     if (int rc = launch_nnls_block(n + 1, m, B, ws + L.An, (int64_t)L.total, P.bn, 0, nullptr, work, P.y, P.rn, P.nnls_status,
                                    P.nnls_iters, st))
         return rc;
-    hipLaunchKernelGGL(qp_block_recover_kernel, dim3((unsigned)B), dim3(kBlkThreads), 0, st, P);
+    if (small) hipLaunchKernelGGL(qp_block_recover_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), 0, st, P);
+    else hipLaunchKernelGGL(qp_block_recover_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), 0, st, P);
     return check_launch("qp_block_recover_kernel");
 }
 }  // namespace

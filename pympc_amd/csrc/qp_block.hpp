@@ -1,5 +1,5 @@
-// Strictly convex QPs of 64 .. 255 variables: pnnls.quadratic_program (/root/reference/pympc/optimization/solvers/
-// pnnls.py:149-241) around nnls_block_kernel (nnls_block.hpp), one workgroup of 256 threads per problem.
+// Strictly convex QPs of 64 .. 511 variables: pnnls.quadratic_program (/root/reference/pympc/optimization/solvers/
+// pnnls.py:149-241) around nnls_block_kernel (nnls_block.hpp), one workgroup of 256 or 512 threads per problem.
 //
 // The wave path (qp_prepare.hpp, qp_wave.hpp) keeps the three n x n factors of a problem in LDS and one row of the
 // (n + 1)-row NNLS matrix per lane, which ends at n = 63.  Here the factors live in device memory (they stay in L2: 2 x
@@ -60,8 +60,10 @@ struct QpBlockParams {
     int32_t *status, *iters;
 };
 
-__global__ void __launch_bounds__(kBlkThreads) qp_block_prepare_kernel(QpBlockParams P)
+template <int T>
+__global__ void __launch_bounds__(T) qp_block_prepare_kernel(QpBlockParams P)
 {
+    constexpr int kBlkThreads = T;
     __shared__ double fs[kBlkThreads], vs[kBlkThreads], hs[kBlkThreads];
     const int t = threadIdx.x, n = P.n, m = P.m;
     const long long k = blockIdx.x;
@@ -167,9 +169,11 @@ __global__ void __launch_bounds__(kBlkThreads) qp_block_prepare_kernel(QpBlockPa
     }
 }
 
-__global__ void __launch_bounds__(kBlkThreads) qp_block_recover_kernel(QpBlockParams P)
+template <int T>
+__global__ void __launch_bounds__(T) qp_block_recover_kernel(QpBlockParams P)
 {
-    __shared__ double gs[kBlkThreads], wv[kBlkThreads], xs[kBlkThreads], slots[8];
+    constexpr int kBlkThreads = T, kBlkWaves = T / 64;
+    __shared__ double gs[kBlkThreads], wv[kBlkThreads], xs[kBlkThreads], slots[16];
     const int t = threadIdx.x, n = P.n, m = P.m;
     const long long k = blockIdx.x;
     const QpBlockLayout Q = qp_block_layout(n, m);
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(kBlkThreads) qp_block_recover_kernel(QpBlockPa
     const double *ws = P.ws + k * (long long)Q.total;
     const double *Li = ws + Q.Li, *At = ws + Q.At, *mv = ws + Q.mv;
     double *y = P.y + k * (long long)m;
-    BlockReduce red{slots, 0};
+    BlockReduce<T / 64> red{slots, 0};
     const int words = (m + 31) / 32;
     int st = 0;
     if (P.notpd[k]) st = 4;

@@ -3,8 +3,8 @@
 
     python3 benchmarks/block_launch.py [nnls|qp] [reps]
 
-nnls: random dense problems of 128 x 300 and 256 x 500 (one, and a batch of 512); qp: strictly convex QPs of 100 and
-255 variables (one, and a batch).  Every line also times the oracle (one scalar core) on the first problem of the batch.
+nnls: random dense problems of 128 x 300, 256 x 500 and 512 x 700 (one, and a batch); qp: strictly convex QPs of 100,
+255 and 500 variables (one, and a batch).  Every line also times the oracle (one scalar core) on the first problem of the batch.
 Prints one JSON line per shape."""
 import json
 import os
@@ -25,7 +25,7 @@ def main():
     rng = np.random.RandomState(0)
     if what == "nnls":
         from pympc_amd.optimization.solvers.hip_lp import nnls_batch
-        for rows, cols, B in ((128, 300, 1), (256, 500, 1), (128, 300, 512), (256, 500, 512)):
+        for rows, cols, B in ((128, 300, 1), (256, 500, 1), (512, 700, 1), (128, 300, 512), (256, 500, 512), (512, 700, 256)):
             A = torch.as_tensor(rng.randn(B, rows, cols), device='cuda'); b = torch.as_tensor(rng.randn(B, rows), device='cuda')
             nnls_batch(A, b); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -38,7 +38,7 @@ def main():
                                   oracle_ms_one_problem=round(cpu, 3), oracle_iters=[int(it[0]), int(it[1])], ok=bool((st == 0).all()))), flush=True)
     else:
         from pympc_amd.optimization.solvers.hip import quadratic_program_batch
-        for n, m, B in ((100, 300, 1), (255, 1000, 1), (100, 300, 512), (255, 1000, 256)):
+        for n, m, B in ((100, 300, 1), (255, 1000, 1), (500, 1000, 1), (100, 300, 512), (255, 1000, 256), (500, 1000, 256)):
             G = rng.randn(n, n); H = G.dot(G.T) / n + np.eye(n); A = rng.randn(m, n)
             F = rng.randn(B, n); Bv = A.dot(rng.randn(n))[None, :] + rng.rand(B, m)
             Ht, At, Ft, Bt = [torch.as_tensor(a, device='cuda') for a in (H, A, F, Bv)]

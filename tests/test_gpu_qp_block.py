@@ -160,3 +160,20 @@ def test_linear_mpc_with_horizon_70_end_to_end(oracle):
     k = int(np.where(ok)[0][0])
     u_seq, V = ctrl.feedforward(xs[k])
     assert abs(V - ref["min"][k]) < 1e-7 * max(1.0, abs(ref["min"][k])) and abs(ctrl.feedback(xs[k])[0] - ref["argmin"][k, 0]) < 1e-6
+
+
+def test_polyhedron_empty_in_many_dimensions(oracle):
+    """Polyhedron.empty (the minimum-norm QP of polyhedron.py:505-526) in 80 and 200 dimensions: the reference's own
+    formulation now that the QP takes that many variables, with and without equalities."""
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    rng = np.random.RandomState(17)
+    for n in (80, 200):
+        P = Polyhedron.from_bounds(-np.ones(n), np.ones(n))
+        assert not P.empty
+        A = np.vstack((P.A, np.ones((1, n)), -np.ones((1, n)))); b = np.concatenate((P.b, [-1.0, 0.5]))      # sum <= -1 and sum >= -0.5
+        assert Polyhedron(A, b).empty
+        C = rng.randn(3, n); d = C.dot(rng.uniform(-.5, .5, n))
+        assert not Polyhedron(P.A, P.b, C, d).empty
+        assert Polyhedron(P.A, P.b, np.ones((1, n)), np.array([n + 1.0])).empty                               # sum = n + 1 outside the box
+        ref = oracle.quadratic_program(np.eye(n), np.zeros(n), P.A, P.b, C, d)
+        assert ref['min'] is not None

@@ -235,17 +235,19 @@ class Polyhedron(object):
                 gone = v2 < tol
                 undecided = cand[~gone]
         # 3. the rest in index order, against the reference's current set
-        pending_sure = set(cand.tolist()) - set(undecided.tolist())   # removed when their turn comes
+        pending = np.zeros(m, dtype=bool)                             # removed when their turn comes
+        pending[cand] = True
+        pending[undecided] = False
         for i in undecided:
-            removed[[j for j in pending_sure if j < i]] = True
+            removed[:i] |= pending[:i]
             cur = np.where(~removed)[0]
             rel = f.copy()
             rel[i] += 1.
             sol = linear_program(-E[i], E[cur], rel[cur])
             if - sol['min'] - f[i] < tol:
                 removed[i] = True
-        removed[list(pending_sure)] = True
-        return [int(i) for i in np.where(~removed)[0]]
+        removed |= pending
+        return np.where(~removed)[0].tolist()
 
     STAGED_MIN_FACETS = 2000
 

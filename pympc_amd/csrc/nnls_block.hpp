@@ -1,4 +1,4 @@
-// NNLS and the PNNLS reduction for problems of 65 .. 512 rows: one workgroup of 256 (up to 256 rows) or 512 threads per problem.
+// NNLS and the PNNLS reduction for problems of 65 .. 1024 rows: one workgroup of 256, 512 or 1024 threads per problem (a row per thread).
 //
 // The wave kernel of qp_wave.hpp keeps one row per lane, which ends at 64 rows (QPs of up to 63 variables, LPs in the
 // reference's KKT form of pnnls.py:109-124 with 1 + m + n <= 64).  The reference has no such limit
@@ -28,18 +28,22 @@
 
 namespace pympc {
 
-// One row per thread: 256 threads up to 256 rows, 512 threads (two wavefronts per SIMD, 256 VGPRs each) up to 512.
-constexpr int kBlkThreadsSmall = 256;
-constexpr int kBlkThreadsBig = 512;
-constexpr int kBlkRowsMax = kBlkThreadsBig;
-__host__ __device__ inline int blk_threads(int rows) { return rows <= kBlkThreadsSmall ? kBlkThreadsSmall : kBlkThreadsBig; }
 #ifndef PYMPC_BLK_TRI_COLS
 #define PYMPC_BLK_TRI_COLS 16
 #endif
+// One row per thread: 256 threads up to 256 rows, 512 threads (two wavefronts per SIMD, 256 VGPRs each) up to 512,
+// 1024 threads (four per SIMD, 128 VGPRs each: narrower chunks and unrolls) up to 1024.
+constexpr int kBlkThreadsSmall = 256;
+constexpr int kBlkThreadsBig = 512;
+constexpr int kBlkThreadsHuge = 1024;
+constexpr int kBlkRowsMax = kBlkThreadsHuge;
+__host__ __device__ inline int blk_threads(int rows)
+{
+    return rows <= kBlkThreadsSmall ? kBlkThreadsSmall : rows <= kBlkThreadsBig ? kBlkThreadsBig : kBlkThreadsHuge;
+}
 // Columns of the triangular factor staged in LDS at a time.  One problem alone runs the same with 8, 16 or 32 (the solve
 // is a latency chain either way); a batch gains from the smaller footprint (256 x 500: 56 instead of 84 KB of LDS, two
 // workgroups per CU instead of one: 512 problems 79 -> 68 ms).
-constexpr int kBlkTriCols = PYMPC_BLK_TRI_COLS;
 
 struct NnlsBlockParams {
     int rows, cols;
@@ -57,11 +61,14 @@ struct NnlsBlockParams {
     int32_t *iters;            // [B x 2] (outer, secondary) or null
 };
 
+__host__ __device__ constexpr int blk_tri_cols(int threads) { return threads >= 1024 ? PYMPC_BLK_TRI_COLS / 2 : PYMPC_BLK_TRI_COLS; }
+__host__ __device__ constexpr int blk_unroll(int threads) { return threads >= 1024 ? 4 : 8; }
 __host__ __device__ inline size_t nnls_block_lds_bytes(int rows, int cols)
 {
-    // doubles: b, zz, u [rows] | x, w [cols] | reduction slots [16] | rotations c, s [rows] | staged factor [kBlkTriCols x rows]
+    const int tc = blk_tri_cols(blk_threads(rows));
+    // doubles: b, zz, u [rows] | x, w [cols] | reduction slots [32] | rotations c, s [rows] | staged factor [kBlkTriCols x rows]
     // ints: index, pos [cols], slotpos [rows]
-    return ((size_t)(5 + kBlkTriCols) * rows + (size_t)2 * cols + 16) * 8 + (((size_t)2 * cols + rows) * 4 + 7) / 8 * 8;
+    return ((size_t)(5 + tc) * rows + (size_t)2 * cols + 32) * 8 + (((size_t)2 * cols + rows) * 4 + 7) / 8 * 8;
 }
 
 // Block reductions over 256 threads through alternating LDS slots: reduction k writes slot k & 1, so a writer of
@@ -160,10 +167,7 @@ __device__ __forceinline__ void blk_givens_fast(double a, double b, double &c, d
 
 // Column passes of one thread over rows l0 .. m of column j (stride n): the loads of kBlkUnroll rows are issued together --
 // a loop of one load and one FMA pays the whole memory latency per row (one workgroup per problem: nothing else hides it).
-#ifndef PYMPC_BLK_UNROLL
-#define PYMPC_BLK_UNROLL 8
-#endif
-constexpr int kBlkUnroll = PYMPC_BLK_UNROLL;
+template <int kBlkUnroll>
 __device__ __forceinline__ double blk_col_dot(const double *a, int n, int j, int l0, int m, const double *vec, double sm)
 {
     int l = l0;
@@ -179,6 +183,7 @@ __device__ __forceinline__ double blk_col_dot(const double *a, int n, int j, int
 }
 // a[l][j] += sm vec[l] for l0 <= l < m; returns the dot product of the NEW entries with `rhs` (the next dual-vector entry
 // of this column, summed in the order blk_col_dot would use: one pass over the matrix less per entering column)
+template <int kBlkUnroll>
 __device__ __forceinline__ double blk_col_axpy_dot(double *a, int n, int j, int l0, int m, const double *vec, double sm, const double *rhs)
 {
     double w = 0.0;
@@ -204,6 +209,7 @@ __device__ __forceinline__ double blk_col_axpy_dot(double *a, int n, int j, int 
 
 // zz[0 .. nsetp) <- solution of the triangular system whose column at position ip sits in slot slotpos[ip] of the
 // packed factor Rs (rows 0 .. ip); zz holds the right-hand side on entry.  Ends with a barrier.
+template <int kBlkTriCols>
 __device__ __forceinline__ void blk_trisolve(const double *Rs, int m, int nsetp, const int *slotpos, double *zz, double *tri)
 {
     const int t = threadIdx.x;
@@ -259,7 +265,7 @@ __device__ __forceinline__ void blk_trisolve(const double *Rs, int m, int nsetp,
 template <int T>
 __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
 {
-    constexpr int kBlkThreads = T;
+    constexpr int kBlkThreads = T, kBlkTriCols = blk_tri_cols(T), kBlkUnroll = blk_unroll(T);
 #ifdef PYMPC_BLK_PROFILE
     long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = wall_clock64();
 #endif
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
     const int t = threadIdx.x, m = P.rows, n = P.cols;
     const long long k = blockIdx.x;
     double *bs = lds, *zz = bs + m, *uu = zz + m, *xs = uu + m, *ws = xs + n, *slots = ws + n;
-    double *rotc = slots + 16, *rots = rotc + m;   // rotations of a deletion, by the row they end in
+    double *rotc = slots + 32, *rots = rotc + m;   // rotations of a deletion, by the row they end in
     double *tri = rots + m;
     int *index = reinterpret_cast<int *>(tri + (size_t)kBlkTriCols * m), *pos = index + n, *slotpos = pos + n;
     BlockReduce<T / 64> red{slots, 0};
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
         if (!dual_ready) {
             for (int j = t; j < n; j += kBlkThreads) {
                 if (pos[j] < nsetp) continue;
-                ws[j] = blk_col_dot(a, n, j, nsetp, m, bs, 0.0);
+                ws[j] = blk_col_dot<kBlkUnroll>(a, n, j, nsetp, m, bs, 0.0);
             }
             __syncthreads();
         }
@@ -364,14 +370,14 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
                 for (int c = t; c < n; c += kBlkThreads) {
                     if (pos[c] < nsetp) continue;
                     const double ap = a[(size_t)piv * n + c];
-                    double sm = blk_col_dot(a, n, c, piv + 1, m, uu, ap * up);
+                    double sm = blk_col_dot<kBlkUnroll>(a, n, c, piv + 1, m, uu, ap * up);
                     // (bs is the new right-hand side already and rows piv + 1 .. are the rows the next dual vector sums)
                     if (sm != 0.0) {
                         sm *= binv;
                         a[(size_t)piv * n + c] = fma(sm, up, ap);
-                        ws[c] = blk_col_axpy_dot(a, n, c, piv + 1, m, uu, sm, bs);
+                        ws[c] = blk_col_axpy_dot<kBlkUnroll>(a, n, c, piv + 1, m, uu, sm, bs);
                     } else {
-                        ws[c] = blk_col_dot(a, n, c, piv + 1, m, bs, 0.0);
+                        ws[c] = blk_col_dot<kBlkUnroll>(a, n, c, piv + 1, m, bs, 0.0);
                     }
                 }
                 dual_ready = true;
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
         }
         __syncthreads();
         BLK_TICK(2)
-        blk_trisolve(Rs, m, nsetp, slotpos, zz, tri);   // zz == bs here
+        blk_trisolve<kBlkTriCols>(Rs, m, nsetp, slotpos, zz, tri);   // zz == bs here
         BLK_TICK(3)
         // secondary loop
         for (;;) {
@@ -496,7 +502,7 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
             if (t < m) zz[t] = bs[t];
             __syncthreads();
             BLK_TICK(4)
-            blk_trisolve(Rs, m, nsetp, slotpos, zz, tri);
+            blk_trisolve<kBlkTriCols>(Rs, m, nsetp, slotpos, zz, tri);
             BLK_TICK(3)
         }
         if (mode != 0) break;
@@ -517,12 +523,12 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
     }
 }
 
-// ---------------------------------------------------------------------------------------- PNNLS, 65 .. 512 rows
+// ---------------------------------------------------------------------------------------- PNNLS, 65 .. 1024 rows
 // pnnls_reduce_kernel of nnls_raw.hpp with one row per thread: Householder QR of B with column pivoting applied to
 // [A | c].  LDS: B (rows x (nu | 1)), the reflector, reduction slots, the permutation.
 __host__ __device__ inline size_t pnnls_block_lds_bytes(int rows, int nu)
 {
-    return ((size_t)rows * (nu | 1) + rows + 16) * 8 + (size_t)(nu + 1) * 4;
+    return ((size_t)rows * (nu | 1) + rows + 32) * 8 + (size_t)(nu + 1) * 4;
 }
 
 template <int T>
@@ -533,7 +539,7 @@ __global__ void __launch_bounds__(T) pnnls_reduce_block_kernel(PnnlsParams P)
     const long long k = blockIdx.x;
     const int rows = P.rows, cols = P.cols, nu = P.nu, ld = nu | 1, t = threadIdx.x;
     double *Bs = lds, *vv = Bs + (size_t)rows * ld, *slots = vv + rows;
-    int *perm = reinterpret_cast<int *>(slots + 16);
+    int *perm = reinterpret_cast<int *>(slots + 32);
     BlockReduce<T / 64> red{slots, 0};
     const double *A = P.A + k * (long long)rows * cols;
     double *QA = P.QA + k * (long long)rows * cols;

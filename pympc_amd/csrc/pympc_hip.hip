@@ -545,6 +545,7 @@ size_t pympc_nnls_workspace_doubles(int rows, int cols, int64_t B)
 {
     const int R = rows < 2 ? 2 : rows;
     if (rows < 1 || cols < 1 || rows > kBlkRowsMax || cols > kMMax || B < 0) return 0;
+    if (R - 1 > kNMax && nnls_block_lds_bytes(rows, cols) > kLdsBytes) return 0;
     if (R - 1 > kNMax) return ((size_t)rows * cols + (size_t)rows * rows) * (size_t)B + 32;   // nnls_block_kernel: a working copy of each matrix and its triangular factor
     return (ws_layout(R - 1, cols, 0).total + (size_t)R) * (size_t)B + 32;
 }
@@ -561,12 +562,17 @@ int launch_nnls_block(int rows, int cols, int64_t B, const double *A, int64_t a_
     Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = b_stride; Q.skip_rows = skip_rows;
     Q.work = work; Q.factor = work + (size_t)rows * cols * (size_t)B; Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
     const size_t lds = nnls_block_lds_bytes(rows, cols);
-    if (blk_threads(rows) == kBlkThreadsSmall) {
+    if (lds > kLdsBytes) return fail(PYMPC_ERR_UNSUPPORTED, "NNLS %d x %d needs %zu B of LDS (160 KiB available)", rows, cols, lds);
+    const int T = blk_threads(rows);
+    if (T == kBlkThreadsSmall) {
         if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsSmall>, lds)) return rc;
         hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), lds, st, Q);
-    } else {
+    } else if (T == kBlkThreadsBig) {
         if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsBig>, lds)) return rc;
         hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), lds, st, Q);
+    } else {
+        if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsHuge>, lds)) return rc;
+        hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsHuge>, dim3((unsigned)B), dim3(kBlkThreadsHuge), lds, st, Q);
     }
     return check_launch("nnls_block_kernel");
 }
@@ -632,12 +638,16 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
     hipStream_t st = (hipStream_t)stream;
     if (rows > 64) {   // one row per thread of a workgroup instead of one per lane (nnls_block.hpp)
         const size_t ldsb = pnnls_block_lds_bytes(rows, nu);
-        if (blk_threads(rows) == kBlkThreadsSmall) {
+        const int T = blk_threads(rows);
+        if (T == kBlkThreadsSmall) {
             if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsSmall>, ldsb)) return rc;
             hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), ldsb, st, R);
-        } else {
+        } else if (T == kBlkThreadsBig) {
             if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsBig>, ldsb)) return rc;
             hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), ldsb, st, R);
+        } else {
+            if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsHuge>, ldsb)) return rc;
+            hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsHuge>, dim3((unsigned)B), dim3(kBlkThreadsHuge), ldsb, st, R);
         }
         if (int rc = check_launch("pnnls_reduce_block_kernel")) return rc;
         if (int rc = launch_nnls_block(rows, cols, B, R.QA, (int64_t)rows * cols, R.Qc, rows, R.rank, ws, v, rnorm, status, iters, st)) return rc;
@@ -670,6 +680,7 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)
 {
     if (n < 1 || m < 1 || n > kQpBlockNMax || m > kMMax || B < 0) return 0;
+    if (n > kNMax && nnls_block_lds_bytes(n + 1, m) > kLdsBytes) return 0;
     if (n > kNMax) {   // qp_block.hpp: factors and NNLS matrix per problem, the NNLS kernel's working copy, y, scalars
         const size_t per = qp_block_layout(n, m).total + (size_t)(n + 1) * m + (size_t)(n + 1) * (n + 1) + (size_t)m + 4;
         return per * (size_t)B + (size_t)n + 2 + 32;
@@ -697,15 +708,17 @@ int qp_block_solve(int n, int m, int64_t B, const double *H, int64_t h_stride, c
     P.nnls_iters = P.nnls_status + (size_t)B;
     P.notpd = P.nnls_iters + 2 * (size_t)B;
     P.argmin = argmin; P.vmin = vmin; P.mult = mult; P.active = active; P.status = status; P.iters = iters;
-    const bool small = blk_threads(n + 1) == kBlkThreadsSmall;
-    if (small) hipLaunchKernelGGL(qp_block_prepare_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), 0, st, P);
-    else hipLaunchKernelGGL(qp_block_prepare_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), 0, st, P);
+    const int T = blk_threads(n + 1);
+    if (T == kBlkThreadsSmall) hipLaunchKernelGGL(qp_block_prepare_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), 0, st, P);
+    else if (T == kBlkThreadsBig) hipLaunchKernelGGL(qp_block_prepare_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), 0, st, P);
+    else hipLaunchKernelGGL(qp_block_prepare_kernel<kBlkThreadsHuge>, dim3((unsigned)B), dim3(kBlkThreadsHuge), 0, st, P);
     if (int rc = check_launch("qp_block_prepare_kernel")) return rc;
     if (int rc = launch_nnls_block(n + 1, m, B, ws + L.An, (int64_t)L.total, P.bn, 0, nullptr, work, P.y, P.rn, P.nnls_status,
                                    P.nnls_iters, st))
         return rc;
-    if (small) hipLaunchKernelGGL(qp_block_recover_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), 0, st, P);
-    else hipLaunchKernelGGL(qp_block_recover_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), 0, st, P);
+    if (T == kBlkThreadsSmall) hipLaunchKernelGGL(qp_block_recover_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), 0, st, P);
+    else if (T == kBlkThreadsBig) hipLaunchKernelGGL(qp_block_recover_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), 0, st, P);
+    else hipLaunchKernelGGL(qp_block_recover_kernel<kBlkThreadsHuge>, dim3((unsigned)B), dim3(kBlkThreadsHuge), 0, st, P);
     return check_launch("qp_block_recover_kernel");
 }
 }  // namespace

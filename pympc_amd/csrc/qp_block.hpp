@@ -1,5 +1,5 @@
-// Strictly convex QPs of 64 .. 511 variables: pnnls.quadratic_program (/root/reference/pympc/optimization/solvers/
-// pnnls.py:149-241) around nnls_block_kernel (nnls_block.hpp), one workgroup of 256 or 512 threads per problem.
+// Strictly convex QPs of 64 .. 1023 variables: pnnls.quadratic_program (/root/reference/pympc/optimization/solvers/
+// pnnls.py:149-241) around nnls_block_kernel (nnls_block.hpp), one workgroup of 256, 512 or 1024 threads per problem.
 //
 // The wave path (qp_prepare.hpp, qp_wave.hpp) keeps the three n x n factors of a problem in LDS and one row of the
 // (n + 1)-row NNLS matrix per lane, which ends at n = 63.  Here the factors live in device memory (they stay in L2: 2 x
@@ -173,7 +173,7 @@ template <int T>
 __global__ void __launch_bounds__(T) qp_block_recover_kernel(QpBlockParams P)
 {
     constexpr int kBlkThreads = T, kBlkWaves = T / 64;
-    __shared__ double gs[kBlkThreads], wv[kBlkThreads], xs[kBlkThreads], slots[16];
+    __shared__ double gs[kBlkThreads], wv[kBlkThreads], xs[kBlkThreads], slots[32];
     const int t = threadIdx.x, n = P.n, m = P.m;
     const long long k = blockIdx.x;
     const QpBlockLayout Q = qp_block_layout(n, m);

@@ -5,7 +5,7 @@ is the same switch with ONE backend, `'hip'`, which is also the default -- none 
 `solver=` (polyhedron.py:444,523,756, parametric_programs.py:173, ...), so the default string is the global
 switch.  `'pnnls'` is accepted as an alias so that code written against the reference runs unchanged; there is
 no CPU path behind it.  `'hip_kkt'` selects, for LPs, the reference's OWN formulation on the device (the KKT system
-of pnnls.py:109-124 solved as a PNNLS and decided by its residual, :137; 1 + m + n <= 512): the default LP kernel is a
+of pnnls.py:109-124 solved as a PNNLS and decided by its residual, :137; 1 + m + n <= 1024): the default LP kernel is a
 dual active-set method that decides feasibility row by row, and the two differ for LPs that are infeasible or
 unbounded by a margin between 1e-9 and 1e-7.
 """

@@ -120,9 +120,9 @@ class PreparedMpqp(object):
         if nd == 0:
             nmax, mmax = _hip.limits()
             if self.n <= nmax or lib.pympc_qp_workspace_doubles(self.n, self.m, 1) == 0:
-                raise NotImplementedError('mpQP with n=%d, m=%d is outside the kernel limits (n<=%d prepared once, n<=511 '
+                raise NotImplementedError('mpQP with n=%d, m=%d is outside the kernel limits (n<=%d prepared once, n<=1023 '
                                           'solved per state, m<=%d)' % (self.n, self.m, nmax, mmax))
-            # 64 .. 511 variables: no prepared form (the wave kernel's factors live in LDS); every state is solved as
+            # 64 .. 1023 variables: no prepared form (the wave kernel's factors live in LDS); every state is solved as
             # a QP of its own by the workgroup-per-problem kernels of csrc/qp_block.hpp (solve_batch below)
             self.large = True
             self.g = float(g)
@@ -349,7 +349,7 @@ def quadratic_program_batch(H, f, A, b, tol=TOL, n_eq=0, want_mult=True, want_ac
     nd = lib.pympc_qp_workspace_doubles(n, m, B)
     if nd == 0:
         nmax, mmax = _hip.limits()
-        raise NotImplementedError('QP with n=%d, m=%d is outside the kernel limits (n<=%d on the wave kernel, n<=511 on the '
+        raise NotImplementedError('QP with n=%d, m=%d is outside the kernel limits (n<=%d on the wave kernel, n<=1023 on the '
                                   'workgroup kernel of csrc/qp_block.hpp, m<=%d)' % (n, m, nmax, mmax))
     ws = torch.empty(nd, dtype=torch.float64, device=dev)
     out = _alloc_outputs(B, n, m, dev, want_mult, want_active, want_iters)

@@ -133,7 +133,7 @@ def nnls_batch(A, b):
     cols = A.shape[-1]
     nd = lib.pympc_nnls_workspace_doubles(rows, cols, B)
     if nd == 0:
-        raise NotImplementedError('NNLS with %d rows, %d columns is outside the kernel limits (512 rows, 2048 columns)'
+        raise NotImplementedError('NNLS with %d rows, %d columns is outside the kernel limits (1024 rows, 2048 columns)'
                                   % (rows, cols))
     ws = torch.empty(nd, dtype=torch.float64, device=dev)
     x = torch.empty((B, cols), dtype=torch.float64, device=dev)
@@ -165,7 +165,7 @@ def pnnls_batch(A, B, c):
     nu = Bm.shape[2]
     nd = lib.pympc_pnnls_workspace_doubles(rows, cols, nu, Bn)
     if nd == 0:
-        raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (512 rows, 2048 + 64; rows x free variables within 160 KiB of LDS)'
+        raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (1024 rows, 2048 + 64; rows x free variables within 160 KiB of LDS)'
                                   % (rows, cols, nu))
     ws = torch.empty(nd, dtype=torch.float64, device=dev)
     v = torch.empty((Bn, cols), dtype=torch.float64, device=dev)
@@ -187,7 +187,7 @@ def pnnls(A, B, c):
 
 
 def linear_program_pnnls(f, A, b, C=None, d=None, tol=TOL):
-    """The reference's own LP formulation on the device, for LPs of 1 + m + n <= 512 rows after folding equalities and
+    """The reference's own LP formulation on the device, for LPs of 1 + m + n <= 1024 rows after folding equalities and
     n <= 64 (up to 64 rows on the wave kernel, beyond on the workgroup-per-problem kernel of csrc/nnls_block.hpp):
     the KKT system of pnnls.py:109-124 solved by pnnls(), solvable iff the residual is below tol (pnnls.py:137).
     linear_program() reaches the same primal-dual pair with a dual active-set method in n-space and decides

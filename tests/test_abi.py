@@ -37,8 +37,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.pympc_mpqp_workspace_doubles(63, 100, 4) > 0
     assert lib.pympc_mpqp_workspace_doubles(63, 100, 8) == 0           # factor matrices + Hux beyond 160 KiB of LDS
     assert lib.pympc_mpqp_multi_workspace_doubles(63, 100, 8, 10) == 0
-    assert lib.pympc_nnls_workspace_doubles(64, 2048, 3) > 0 and lib.pympc_nnls_workspace_doubles(513, 10, 3) == 0
-    assert lib.pympc_nnls_workspace_doubles(65, 10, 3) >= 65 * 10 * 3             # 65 .. 512 rows: a working copy per problem
+    assert lib.pympc_nnls_workspace_doubles(64, 2048, 3) > 0 and lib.pympc_nnls_workspace_doubles(1025, 10, 3) == 0
+    assert lib.pympc_nnls_workspace_doubles(65, 10, 3) >= 65 * 10 * 3             # 65 .. 1024 rows: a working copy per problem
     assert lib.pympc_pnnls_workspace_doubles(64, 100, 64, 2) > 0 and lib.pympc_pnnls_workspace_doubles(64, 100, 65, 2) == 0
 
 

@@ -44,7 +44,7 @@ def test_limits_are_errors_not_fallbacks():
     from pympc_amd.optimization.solvers.hip import quadratic_program_batch
     from pympc_amd.optimization.solvers.hip_lp import linear_program_batch
     nmax, mmax = _hip.limits()
-    nbig = 511      # per-problem QPs beyond the wave kernel's nmax go to the workgroup kernels (csrc/qp_block.hpp) up to here
+    nbig = 1023      # per-problem QPs beyond the wave kernel's nmax go to the workgroup kernels (csrc/qp_block.hpp) up to here
     res = quadratic_program_batch(np.eye(nmax + 1), np.zeros((1, nmax + 1)), np.ones((2, nmax + 1)), np.ones((1, 2)))
     assert res.feasible.all() and np.abs(res.numpy('argmin')).max() < 1e-12
     with pytest.raises(NotImplementedError):

@@ -1,5 +1,5 @@
 """NNLS / PNNLS / the reference's LP form beyond 64 rows: the workgroup-per-problem kernels of csrc/nnls_block.hpp
-(65 .. 512 rows; 256 threads up to 256 rows, 512 beyond) against the oracle's Lawson-Hanson and against scipy's own regression problems, unreduced
+(65 .. 1024 rows; 256, 512 or 1024 threads, a row per thread) against the oracle's Lawson-Hanson and against scipy's own regression problems, unreduced
 (tests/golden/scipy_nnls_tests.npz; test_gpu_nnls.py runs the same files through a QR reduction on the wave kernel).
 Tolerances: residual norms to 1e-9 relative, unique minimisers to 1e-8 (fp64; the block kernel sums column-wise dot
 products in one thread and row-wise norms through a tree, the oracle serially)."""
@@ -15,7 +15,7 @@ def test_nnls_block_random_vs_oracle(oracle):
     from pympc_amd.optimization.solvers.hip_lp import nnls_batch
     rng = np.random.RandomState(19)
     for rows, cols, B in ((65, 30, 6), (100, 300, 6), (128, 128, 4), (200, 64, 4), (256, 500, 3), (255, 2048, 2), (70, 1, 3),
-                          (257, 90, 3), (300, 400, 2), (512, 300, 2), (511, 2048, 1)):
+                          (257, 90, 3), (300, 400, 2), (512, 300, 2), (511, 2048, 1), (513, 120, 2), (800, 500, 1), (1024, 300, 1)):
         A = rng.randn(B, rows, cols); b = rng.randn(B, rows)
         x, rn, st = nnls_batch(A, b)
         x, rn, st = x.cpu().numpy(), rn.cpu().numpy(), st.cpu().numpy()
@@ -69,7 +69,7 @@ def test_nnls_block_scipy_regression_problems_unreduced():
     ran = []
     for k in range(int(g["count"])):
         A, b = g["A%d" % k], g["b%d" % k]
-        if not bool(g["ok%d" % k]) or not (64 < A.shape[0] <= 512) or A.shape[1] > 2048:
+        if not bool(g["ok%d" % k]) or not (64 < A.shape[0] <= 1024) or A.shape[1] > 2048:
             continue
         x, rn = nnls(A, b)
         xs = g["x%d" % k]
@@ -94,13 +94,13 @@ def test_nnls_block_iteration_limit():
         with pytest.raises(RuntimeError, match="Maximum number of iterations"):
             nnls(A, b)
     with pytest.raises(NotImplementedError):
-        nnls(rng.randn(513, 4), rng.randn(513))
+        nnls(rng.randn(1025, 4), rng.randn(1025))
 
 
 def test_pnnls_block_random_vs_oracle(oracle):
     from pympc_amd.optimization.solvers.hip_lp import pnnls, pnnls_batch
     rng = np.random.RandomState(6)
-    for rows, nv, nu in ((65, 40, 3), (100, 150, 20), (128, 60, 64), (200, 300, 10), (256, 100, 33), (300, 150, 40), (512, 200, 30)):
+    for rows, nv, nu in ((65, 40, 3), (100, 150, 20), (128, 60, 64), (200, 300, 10), (256, 100, 33), (300, 150, 40), (512, 200, 30), (900, 300, 12)):
         A = rng.randn(rows, nv); B = rng.randn(rows, nu); c = rng.randn(rows)
         v, u, r = pnnls(A, B, c)
         vo, uo, ro = oracle.pnnls(A, B, c)
@@ -126,13 +126,13 @@ def test_pnnls_block_random_vs_oracle(oracle):
 
 def test_lp_in_the_reference_form_beyond_64_rows(oracle):
     """linear_program_pnnls (the KKT system of pnnls.py:109-124, decided by the residual as pnnls.py:137 does) on LPs
-    with 1 + m + n up to 512: optimum, multipliers and the solvable / not solvable decision against the oracle's
+    with 1 + m + n up to 1024: optimum, multipliers and the solvable / not solvable decision against the oracle's
     linear_program -- including LPs that are infeasible by a margin between the two decision rules' tolerances, where
     the active-set LP kernel and the reference differ."""
     from pympc_amd.optimization.solvers.hip_lp import linear_program_pnnls
     rng = np.random.RandomState(12)
     n_solv = 0
-    for n, m in ((3, 70), (6, 120), (10, 200), (20, 60), (40, 100), (64, 191), (12, 400), (30, 480)):
+    for n, m in ((3, 70), (6, 120), (10, 200), (20, 60), (40, 100), (64, 191), (12, 400), (30, 480), (10, 900)):
         A = rng.randn(m, n); x0 = rng.randn(n)
         b = A.dot(x0) + rng.rand(m) + 0.1
         A = np.vstack((A, np.eye(n)[: min(n, 4)], -np.eye(n)[: min(n, 4)]))[:m]   # keep m rows

@@ -1,4 +1,4 @@
-"""quadratic_program beyond 63 variables: the workgroup-per-problem path of csrc/qp_block.hpp (64 .. 511 variables;
+"""quadratic_program beyond 63 variables: the workgroup-per-problem path of csrc/qp_block.hpp (64 .. 1023 variables;
 Cholesky, inverses and the NNLS matrix in device memory, nnls_block_kernel, recover) against the oracle's restatement
 of pnnls.py:149-241 -- optimum, minimiser, multipliers and active set, the infeasible and the not-positive-definite
 outcome, equalities folded as the reference folds them, batches with shared and per-problem matrices.
@@ -30,7 +30,7 @@ def _same(sol, ref):
     assert sol['active_set'] == ref['active_set']
 
 
-@pytest.mark.parametrize("n,m", [(64, 50), (64, 300), (100, 200), (150, 600), (255, 400), (200, 1), (256, 300), (400, 500), (511, 700)])
+@pytest.mark.parametrize("n,m", [(64, 50), (64, 300), (100, 200), (150, 600), (255, 400), (200, 1), (256, 300), (400, 500), (511, 700), (512, 300), (1023, 400)])
 def test_quadratic_program_many_variables_vs_oracle(oracle, n, m):
     from pympc_amd.optimization.solvers.hip import quadratic_program
     rng = np.random.RandomState(n + m)
@@ -79,7 +79,7 @@ def test_batches_shared_and_per_problem(oracle):
     for k in range(B):
         _same(res.sol(k), oracle.quadratic_program(Hs[k], F[k], As[k], Bv[k]))
     with pytest.raises(NotImplementedError):
-        quadratic_program_batch(np.eye(512), np.zeros((1, 512)), np.ones((1, 512)), np.ones((1, 1)))
+        quadratic_program_batch(np.eye(1024), np.zeros((1, 1024)), np.ones((1, 1024)), np.ones((1, 1)))
 
 
 def test_iteration_limit_raises_like_scipy():

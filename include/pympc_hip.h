@@ -167,7 +167,7 @@ int pympc_mpqp_solve_batch_static(int n, int m, int p, const double *ws, const d
  * Reference: pympc/optimization/solvers/pnnls.py:149-241 once per problem (programs.py:57-105); callers
  * polyhedron.py:523 (empty), controllers.py:668-680 + parametric_programs.py:173 (get_mpqp(ms).solve).
  * H [B x n x n] (or [n x n] with h_stride 0), f [B x n], A [B x m x n] (a_stride 0: shared), b [B x m].
- * n <= 63: one wavefront per problem (pympc_hip_limits); 64 <= n <= 1023 (m <= 2048): one workgroup per problem with
+ * n <= 63: one wavefront per problem (pympc_hip_limits); 64 <= n <= 1023 or 2048 < m <= 32768: one workgroup per problem with
  * the factors in device memory (csrc/qp_block.hpp) -- same outputs, same statuses (PYMPC_NOT_PD included).
  * ------------------------------------------------------------------------------------------------- */
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B);
@@ -245,7 +245,7 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
 /* -------------------------------------------------------------------------------------------------
  * Raw NNLS and PNNLS: the two numerical cores under the QP / LP transformations.
  *
- * pympc_nnls_batch: B problems  min |A_k x - b_k|  s.t. x >= 0  of equal shape (rows <= 1024, cols <= 2048; up to
+ * pympc_nnls_batch: B problems  min |A_k x - b_k|  s.t. x >= 0  of equal shape (rows <= 1024, cols <= 32768; up to
  * 64 rows one wavefront per problem with a row per lane, from 65 rows one workgroup per problem with a row per
  * thread, csrc/nnls_block.hpp -- same algorithm, same selection rules).
  * Reference: scipy.optimize.nnls(A, b) as called at pympc/optimization/solvers/pnnls.py:36 and :218 (third party,
@@ -253,7 +253,7 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
  * shared (a_stride 0); b [B x rows].  Outputs x [B x cols], rnorm [B] = |A x - b| (may be NULL), status [B]
  * (PYMPC_OPTIMAL / PYMPC_MAXITER: scipy raises RuntimeError there), iters [B x 2] (may be NULL).
  *
- * pympc_pnnls_batch: B problems  min |A_k v + B_k u - c_k|  s.t. v >= 0  (rows <= 1024, cols <= 2048, nu <= 64; beyond 64 rows also rows * nu * 8 bytes within the 160 KiB of LDS).
+ * pympc_pnnls_batch: B problems  min |A_k v + B_k u - c_k|  s.t. v >= 0  (rows <= 1024, cols <= 32768, nu <= 64; beyond 64 rows also rows * nu * 8 bytes within the 160 KiB of LDS).
  * Reference: pnnls(A, B, c) of pympc/optimization/solvers/pnnls.py:5-39 (returns v, u, r); the reference projects
  * with the dense matrix I - B pinv(B) (:30-33), here u is eliminated by a column-pivoted Householder QR of B (same
  * residual; u is the minimum-norm solution when B is rank deficient, as pinv gives).  A [B x rows x cols],

@@ -55,6 +55,7 @@ struct NnlsBlockParams {
     const int32_t *skip_rows;  // per problem: the first skip_rows[k] rows count as zero (PNNLS), or null
     double *work;              // [B x rows x cols] working copy of the matrix
     double *factor;            // [B x rows x rows] the triangular factor, a slot of `rows` doubles per column in P
+    double *colvec;            // [B x 3 cols] x, w, index and pos of the COLSG instances (more columns than the LDS holds)
     double *x;                 // [B x cols]
     double *rnorm;             // [B] or null
     int32_t *status;           // [B]
@@ -63,9 +64,11 @@ struct NnlsBlockParams {
 
 __host__ __device__ constexpr int blk_tri_cols(int threads) { return threads >= 1024 ? PYMPC_BLK_TRI_COLS / 2 : PYMPC_BLK_TRI_COLS; }
 __host__ __device__ constexpr int blk_unroll(int threads) { return threads >= 1024 ? 4 : 8; }
-__host__ __device__ inline size_t nnls_block_lds_bytes(int rows, int cols)
+constexpr int kBlkColsMax = 32768;   // columns with the vectors over columns in device memory (COLSG instances)
+__host__ __device__ inline size_t nnls_block_lds_bytes(int rows, int cols, bool colsg = false)
 {
     const int tc = blk_tri_cols(blk_threads(rows));
+    if (colsg) return ((size_t)(5 + tc) * rows + 32) * 8 + ((size_t)rows * 4 + 7) / 8 * 8;
     // doubles: b, zz, u [rows] | x, w [cols] | reduction slots [32] | rotations c, s [rows] | staged factor [kBlkTriCols x rows]
     // ints: index, pos [cols], slotpos [rows]
     return ((size_t)(5 + tc) * rows + (size_t)2 * cols + 32) * 8 + (((size_t)2 * cols + rows) * 4 + 7) / 8 * 8;
@@ -262,7 +265,9 @@ __device__ __forceinline__ void blk_trisolve(const double *Rs, int m, int nsetp,
 #else
 #define BLK_TICK(slot)
 #endif
-template <int T>
+// COLSG: x, w and the index permutation with its inverse live in device memory instead of LDS (24 bytes per column:
+// beyond ~2000 .. 5000 columns, depending on the rows, they no longer fit beside the staged factor).
+template <int T, bool COLSG>
 __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
 {
     constexpr int kBlkThreads = T, kBlkTriCols = blk_tri_cols(T), kBlkUnroll = blk_unroll(T);
@@ -272,10 +277,13 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
     extern __shared__ double lds[];
     const int t = threadIdx.x, m = P.rows, n = P.cols;
     const long long k = blockIdx.x;
-    double *bs = lds, *zz = bs + m, *uu = zz + m, *xs = uu + m, *ws = xs + n, *slots = ws + n;
+    double *bs = lds, *zz = bs + m, *uu = zz + m, *slots = uu + m;
     double *rotc = slots + 32, *rots = rotc + m;   // rotations of a deletion, by the row they end in
     double *tri = rots + m;
-    int *index = reinterpret_cast<int *>(tri + (size_t)kBlkTriCols * m), *pos = index + n, *slotpos = pos + n;
+    double *colbase = COLSG ? P.colvec + k * 3 * (long long)n : tri + (size_t)kBlkTriCols * m;
+    double *xs = colbase, *ws = xs + n;
+    int *index = reinterpret_cast<int *>(ws + n), *pos = index + n;
+    int *slotpos = COLSG ? reinterpret_cast<int *>(tri + (size_t)kBlkTriCols * m) : pos + n;
     BlockReduce<T / 64> red{slots, 0};
 
     double *a = P.work + k * (long long)m * n;

@@ -544,9 +544,10 @@ int pympc_mpqp_solve_batch_static(int n, int m, int p, const double *ws, const d
 size_t pympc_nnls_workspace_doubles(int rows, int cols, int64_t B)
 {
     const int R = rows < 2 ? 2 : rows;
-    if (rows < 1 || cols < 1 || rows > kBlkRowsMax || cols > kMMax || B < 0) return 0;
-    if (R - 1 > kNMax && nnls_block_lds_bytes(rows, cols) > kLdsBytes) return 0;
-    if (R - 1 > kNMax) return ((size_t)rows * cols + (size_t)rows * rows) * (size_t)B + 32;   // nnls_block_kernel: a working copy of each matrix and its triangular factor
+    if (rows < 1 || cols < 1 || rows > kBlkRowsMax || cols > kBlkColsMax || B < 0) return 0;
+    // nnls_block_kernel (more than 64 rows, or more columns than the wave kernel takes): a working copy of each matrix,
+    // its triangular factor, and the vectors over columns in case they do not fit the LDS
+    if (R - 1 > kNMax || cols > kMMax) return ((size_t)rows * cols + (size_t)rows * rows + 3 * (size_t)cols) * (size_t)B + 32;
     return (ws_layout(R - 1, cols, 0).total + (size_t)R) * (size_t)B + 32;
 }
 
@@ -560,20 +561,21 @@ int launch_nnls_block(int rows, int cols, int64_t B, const double *A, int64_t a_
     Q.rows = rows; Q.cols = cols;
     Q.itmax = (int)std::min<long long>(g_tune.nnls_itmax_factor.load() * (long long)cols, 0x7fffffffLL);
     Q.A = A; Q.a_stride = a_stride; Q.b = b; Q.b_stride = b_stride; Q.skip_rows = skip_rows;
-    Q.work = work; Q.factor = work + (size_t)rows * cols * (size_t)B; Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
-    const size_t lds = nnls_block_lds_bytes(rows, cols);
+    Q.work = work; Q.factor = work + (size_t)rows * cols * (size_t)B; Q.colvec = Q.factor + (size_t)rows * rows * (size_t)B;
+    Q.x = x; Q.rnorm = rnorm; Q.status = status; Q.iters = iters;
+    const bool colsg = nnls_block_lds_bytes(rows, cols) > kLdsBytes;   // the vectors over columns do not fit: device memory
+    const size_t lds = nnls_block_lds_bytes(rows, cols, colsg);
     if (lds > kLdsBytes) return fail(PYMPC_ERR_UNSUPPORTED, "NNLS %d x %d needs %zu B of LDS (160 KiB available)", rows, cols, lds);
     const int T = blk_threads(rows);
-    if (T == kBlkThreadsSmall) {
-        if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsSmall>, lds)) return rc;
-        hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), lds, st, Q);
-    } else if (T == kBlkThreadsBig) {
-        if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsBig>, lds)) return rc;
-        hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), lds, st, Q);
-    } else {
-        if (int rc = allow_lds(nnls_block_kernel<kBlkThreadsHuge>, lds)) return rc;
-        hipLaunchKernelGGL(nnls_block_kernel<kBlkThreadsHuge>, dim3((unsigned)B), dim3(kBlkThreadsHuge), lds, st, Q);
-    }
+#define PYMPC_LAUNCH_NNLS_BLOCK(TT, CG)                                                                          \
+    do {                                                                                                         \
+        if (int rc = allow_lds(nnls_block_kernel<TT, CG>, lds)) return rc;                                       \
+        hipLaunchKernelGGL((nnls_block_kernel<TT, CG>), dim3((unsigned)B), dim3(TT), lds, st, Q);                \
+    } while (0)
+    if (T == kBlkThreadsSmall) { if (colsg) PYMPC_LAUNCH_NNLS_BLOCK(kBlkThreadsSmall, true); else PYMPC_LAUNCH_NNLS_BLOCK(kBlkThreadsSmall, false); }
+    else if (T == kBlkThreadsBig) { if (colsg) PYMPC_LAUNCH_NNLS_BLOCK(kBlkThreadsBig, true); else PYMPC_LAUNCH_NNLS_BLOCK(kBlkThreadsBig, false); }
+    else { if (colsg) PYMPC_LAUNCH_NNLS_BLOCK(kBlkThreadsHuge, true); else PYMPC_LAUNCH_NNLS_BLOCK(kBlkThreadsHuge, false); }
+#undef PYMPC_LAUNCH_NNLS_BLOCK
     return check_launch("nnls_block_kernel");
 }
 }  // namespace
@@ -584,12 +586,13 @@ int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_s
     if (rows < 1 || cols < 1 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_nnls_batch: bad shape %d x %d", rows, cols);
     const int R = rows < 2 ? 2 : rows;
     if (rows > kBlkRowsMax) return fail(PYMPC_ERR_UNSUPPORTED, "rows=%d exceeds the limit of %d rows", rows, kBlkRowsMax);
-    if (cols > kMMax) return fail(PYMPC_ERR_UNSUPPORTED, "cols=%d exceeds the limit of %d columns", cols, kMMax);
+    if (cols > kBlkColsMax) return fail(PYMPC_ERR_UNSUPPORTED, "cols=%d exceeds the limit of %d columns", cols, kBlkColsMax);
     if (a_stride != 0 && a_stride < (int64_t)rows * cols) return fail(PYMPC_ERR_ARG, "a_stride %lld < rows*cols", (long long)a_stride);
     if (B == 0) return 0;
     if (!A || !b || !ws || !x || !status) return fail(PYMPC_ERR_ARG, "pympc_nnls_batch: null pointer");
     if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
-    if (R - 1 > kNMax) return launch_nnls_block(rows, cols, B, A, a_stride, b, rows, nullptr, ws, x, rnorm, status, iters, (hipStream_t)stream);
+    if (R - 1 > kNMax || cols > kMMax)
+        return launch_nnls_block(rows, cols, B, A, a_stride, b, rows, nullptr, ws, x, rnorm, status, iters, (hipStream_t)stream);
     const WsLayout L = ws_layout(R - 1, cols, 0);
     NnlsPrepParams Q;
     memset(&Q, 0, sizeof(Q));
@@ -607,8 +610,8 @@ int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_s
 
 size_t pympc_pnnls_workspace_doubles(int rows, int cols, int nu, int64_t B)
 {
-    if (rows < 1 || rows > kBlkRowsMax || cols < 1 || cols > kMMax || nu < 0 || nu > 64 || B < 0) return 0;
-    if (rows > 64 && pnnls_block_lds_bytes(rows, nu) > kLdsBytes) return 0;   // the reduction keeps B (rows x nu) in LDS
+    if (rows < 1 || rows > kBlkRowsMax || cols < 1 || cols > kBlkColsMax || nu < 0 || nu > 64 || B < 0) return 0;
+    if ((rows > 64 || cols > kMMax) && pnnls_block_lds_bytes(rows, nu) > kLdsBytes) return 0;   // the reduction keeps B (rows x nu) in LDS
     const size_t nn = pympc_nnls_workspace_doubles(rows, cols, B);
     if (nn == 0) return 0;
     return nn + ((size_t)rows * cols + rows + (size_t)rows * nu + nu + 2) * (size_t)B + 32;
@@ -618,9 +621,9 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
                       double *v, double *u, double *rnorm, int32_t *status, int32_t *iters, void *stream)
 {
     if (rows < 1 || cols < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: bad shape");
-    if (rows > kBlkRowsMax || nu > 64 || cols > kMMax || (rows > 64 && pnnls_block_lds_bytes(rows, nu) > kLdsBytes))
+    if (rows > kBlkRowsMax || nu > 64 || cols > kBlkColsMax || ((rows > 64 || cols > kMMax) && pnnls_block_lds_bytes(rows, nu) > kLdsBytes))
         return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of %d rows, 64 free and %d sign-constrained variables "
-                    "(and rows x free variables within 160 KiB of LDS)", rows, cols, nu, kBlkRowsMax, kMMax);
+                    "(and rows x free variables within 160 KiB of LDS)", rows, cols, nu, kBlkRowsMax, kBlkColsMax);
     if (B == 0) return 0;
     if (!A || !c || !ws || !v || !status || (nu > 0 && (!Bm || !u))) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: null pointer");
     if (nu == 0) return pympc_nnls_batch(rows, cols, B, A, (int64_t)rows * cols, c, ws, v, rnorm, status, iters, stream);
@@ -636,7 +639,7 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
     R.rank = R.perm + (size_t)nu * B;
     R.v = v; R.u = u;
     hipStream_t st = (hipStream_t)stream;
-    if (rows > 64) {   // one row per thread of a workgroup instead of one per lane (nnls_block.hpp)
+    if (rows > 64 || cols > kMMax) {   // one row per thread of a workgroup instead of one per lane (nnls_block.hpp)
         const size_t ldsb = pnnls_block_lds_bytes(rows, nu);
         const int T = blk_threads(rows);
         if (T == kBlkThreadsSmall) {
@@ -679,10 +682,9 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
 
 size_t pympc_qp_workspace_doubles(int n, int m, int64_t B)
 {
-    if (n < 1 || m < 1 || n > kQpBlockNMax || m > kMMax || B < 0) return 0;
-    if (n > kNMax && nnls_block_lds_bytes(n + 1, m) > kLdsBytes) return 0;
-    if (n > kNMax) {   // qp_block.hpp: factors and NNLS matrix per problem, the NNLS kernel's working copy, y, scalars
-        const size_t per = qp_block_layout(n, m).total + (size_t)(n + 1) * m + (size_t)(n + 1) * (n + 1) + (size_t)m + 4;
+    if (n < 1 || m < 1 || n > kQpBlockNMax || m > kBlkColsMax || B < 0) return 0;
+    if (n > kNMax || m > kMMax) {   // qp_block.hpp: factors and NNLS matrix per problem, the NNLS kernel's working copy, y, scalars
+        const size_t per = qp_block_layout(n, m).total + (size_t)(n + 1) * m + (size_t)(n + 1) * (n + 1) + 3 * (size_t)m + (size_t)m + 4;
         return per * (size_t)B + (size_t)n + 2 + 32;
     }
     // per-problem prepared workspace + one int32 prepare status per problem (stored after the workspaces)
@@ -701,7 +703,7 @@ int qp_block_solve(int n, int m, int64_t B, const double *H, int64_t h_stride, c
     P.n = n; P.m = m; P.H = H; P.h_stride = h_stride; P.f = f; P.A = A; P.a_stride = a_stride; P.b = b; P.tol = tol;
     P.ws = ws;
     double *work = ws + L.total * (size_t)B;               // [B x (n + 1) x m]
-    P.y = work + ((size_t)(n + 1) * m + (size_t)(n + 1) * (n + 1)) * (size_t)B;   // [B x m] (behind the NNLS kernel's matrices and factors)
+    P.y = work + ((size_t)(n + 1) * m + (size_t)(n + 1) * (n + 1) + 3 * (size_t)m) * (size_t)B;   // [B x m] (behind the NNLS kernel's matrices, factors and column vectors)
     P.rn = P.y + (size_t)m * (size_t)B;                    // [B]
     P.bn = P.rn + (size_t)B;                               // [n + 1] (+ 1 pad)
     P.nnls_status = reinterpret_cast<int32_t *>(P.bn + (((size_t)n + 2) & ~(size_t)1));   // [B], then iters [2B], notpd [B]
@@ -727,7 +729,7 @@ int pympc_qp_solve_batch(int n, int m, int64_t B, const double *H, int64_t h_str
                          int64_t a_stride, const double *b, double tol, double *ws, double *argmin, double *vmin,
                          double *mult, uint32_t *active, int32_t *status, int32_t *iters, void *stream)
 {
-    if (n > kNMax && n <= kQpBlockNMax && m >= 1 && m <= kMMax) {
+    if (n >= 1 && m >= 1 && (n > kNMax || m > kMMax) && n <= kQpBlockNMax && m <= kBlkColsMax) {
         if (B < 0) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: negative batch size");
         if (B == 0) return 0;
         if (!H || !f || !A || !b || !ws || !status) return fail(PYMPC_ERR_ARG, "pympc_qp_solve_batch: null pointer");

@@ -328,8 +328,9 @@ class Polyhedron(object):
         n_max, m_max = _hip.limits()
         if m_qp == 0:
             self._empty = False
-        elif m_qp <= m_max and _hip.load_library().pympc_qp_workspace_doubles(n, m_qp, 1) > 0:
-            # (up to 63 variables on the wave kernel, up to 1023 on the workgroup kernels of csrc/qp_block.hpp)
+        elif _hip.load_library().pympc_qp_workspace_doubles(n, m_qp, 1) > 0:
+            # (up to 63 variables and 2048 rows on the wave kernel, up to 1023 and 32768 on the workgroup kernels of
+            # csrc/qp_block.hpp)
             sol = quadratic_program(np.eye(n), np.zeros(n), self.A, self.b, self.C, self.d)
             self._empty = sol['min'] is None
         elif self.C.shape[0] > 0 and n > min(n_max, _hip.lp_limits()[0]):

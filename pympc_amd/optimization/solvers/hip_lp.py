@@ -133,7 +133,7 @@ def nnls_batch(A, b):
     cols = A.shape[-1]
     nd = lib.pympc_nnls_workspace_doubles(rows, cols, B)
     if nd == 0:
-        raise NotImplementedError('NNLS with %d rows, %d columns is outside the kernel limits (1024 rows, 2048 columns)'
+        raise NotImplementedError('NNLS with %d rows, %d columns is outside the kernel limits (1024 rows, 32768 columns)'
                                   % (rows, cols))
     ws = torch.empty(nd, dtype=torch.float64, device=dev)
     x = torch.empty((B, cols), dtype=torch.float64, device=dev)
@@ -165,7 +165,7 @@ def pnnls_batch(A, B, c):
     nu = Bm.shape[2]
     nd = lib.pympc_pnnls_workspace_doubles(rows, cols, nu, Bn)
     if nd == 0:
-        raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (1024 rows, 2048 + 64; rows x free variables within 160 KiB of LDS)'
+        raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (1024 rows, 32768 + 64; rows x free variables within 160 KiB of LDS)'
                                   % (rows, cols, nu))
     ws = torch.empty(nd, dtype=torch.float64, device=dev)
     v = torch.empty((Bn, cols), dtype=torch.float64, device=dev)

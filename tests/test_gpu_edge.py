@@ -49,8 +49,12 @@ def test_limits_are_errors_not_fallbacks():
     assert res.feasible.all() and np.abs(res.numpy('argmin')).max() < 1e-12
     with pytest.raises(NotImplementedError):
         quadratic_program_batch(np.eye(nbig + 1), np.zeros((1, nbig + 1)), np.ones((2, nbig + 1)), np.ones((1, 2)))
+    # more rows than the wave kernel takes: the workgroup kernels, with their vectors over columns in device memory
+    res = quadratic_program_batch(np.eye(2), np.array([[-3., 0.]]), np.vstack((np.array([[1., 0.]]), np.ones((mmax, 2)))),
+                                  np.concatenate(([1.], np.full(mmax, 50.)))[None, :])
+    assert res.feasible.all() and np.allclose(res.numpy('argmin')[0], [1., 0.], atol=1e-9) and res.sol(0)['active_set'] == [0]
     with pytest.raises(NotImplementedError):
-        quadratic_program_batch(np.eye(2), np.zeros((1, 2)), np.ones((mmax + 1, 2)), np.ones((1, mmax + 1)))
+        quadratic_program_batch(np.eye(2), np.zeros((1, 2)), np.ones((32769, 2)), np.ones((1, 32769)))
     n_lp, m_lp = _hip.lp_limits()
     with pytest.raises(NotImplementedError):
         linear_program_batch(np.zeros((1, n_lp + 1)), np.ones((3, n_lp + 1)), np.ones(3))

@@ -15,7 +15,8 @@ def test_nnls_block_random_vs_oracle(oracle):
     from pympc_amd.optimization.solvers.hip_lp import nnls_batch
     rng = np.random.RandomState(19)
     for rows, cols, B in ((65, 30, 6), (100, 300, 6), (128, 128, 4), (200, 64, 4), (256, 500, 3), (255, 2048, 2), (70, 1, 3),
-                          (257, 90, 3), (300, 400, 2), (512, 300, 2), (511, 2048, 1), (513, 120, 2), (800, 500, 1), (1024, 300, 1)):
+                          (257, 90, 3), (300, 400, 2), (512, 300, 2), (511, 2048, 1), (513, 120, 2), (800, 500, 1), (1024, 300, 1),
+                          (30, 5000, 2), (200, 6000, 1), (600, 2500, 1)):
         A = rng.randn(B, rows, cols); b = rng.randn(B, rows)
         x, rn, st = nnls_batch(A, b)
         x, rn, st = x.cpu().numpy(), rn.cpu().numpy(), st.cpu().numpy()

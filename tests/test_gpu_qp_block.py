@@ -30,7 +30,8 @@ def _same(sol, ref):
     assert sol['active_set'] == ref['active_set']
 
 
-@pytest.mark.parametrize("n,m", [(64, 50), (64, 300), (100, 200), (150, 600), (255, 400), (200, 1), (256, 300), (400, 500), (511, 700), (512, 300), (1023, 400)])
+@pytest.mark.parametrize("n,m", [(64, 50), (64, 300), (100, 200), (150, 600), (255, 400), (200, 1), (256, 300), (400, 500), (511, 700), (512, 300), (1023, 400),
+                                 (10, 3000), (100, 5000), (300, 4000)])
 def test_quadratic_program_many_variables_vs_oracle(oracle, n, m):
     from pympc_amd.optimization.solvers.hip import quadratic_program
     rng = np.random.RandomState(n + m)

@@ -119,10 +119,11 @@ class PreparedMpqp(object):
         self.large = False
         if nd == 0:
             nmax, mmax = _hip.limits()
-            if self.n <= nmax or lib.pympc_qp_workspace_doubles(self.n, self.m, 1) == 0:
+            if lib.pympc_qp_workspace_doubles(self.n, self.m, 1) == 0:
                 raise NotImplementedError('mpQP with n=%d, m=%d is outside the kernel limits (n<=%d prepared once, n<=1023 '
                                           'solved per state, m<=%d)' % (self.n, self.m, nmax, mmax))
-            # 64 .. 1023 variables: no prepared form (the wave kernel's factors live in LDS); every state is solved as
+            # 64 .. 1023 variables, or more than 2048 constraints: no prepared form (the wave kernel's factors and
+            # per-constraint bit sets live in LDS and registers); every state is solved as
             # a QP of its own by the workgroup-per-problem kernels of csrc/qp_block.hpp (solve_batch below)
             self.large = True
             self.g = float(g)

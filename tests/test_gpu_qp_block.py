@@ -178,3 +178,24 @@ def test_polyhedron_empty_in_many_dimensions(oracle):
         assert Polyhedron(P.A, P.b, np.ones((1, n)), np.array([n + 1.0])).empty                               # sum = n + 1 outside the box
         ref = oracle.quadratic_program(np.eye(n), np.zeros(n), P.A, P.b, C, d)
         assert ref['min'] is not None
+
+
+def test_mpqp_with_more_constraints_than_the_prepared_form_takes(oracle):
+    """An mpQP of 6 variables and 2600 constraints (beyond the prepared form's 2048): solved state by state."""
+    from pympc_amd.optimization.solvers.hip import PreparedMpqp
+    rng = np.random.RandomState(21)
+    n, p, m = 6, 3, 2600
+    G = rng.randn(n, n)
+    model = dict(Huu=G.dot(G.T) + np.eye(n), Hux=rng.randn(n, p), Hxx=np.eye(p) * 3.0, fu=rng.randn(n), fx=rng.randn(p), g=1.5,
+                 Au=rng.randn(m, n), Ax=0.3 * rng.randn(m, p), b=1.0 + rng.rand(m))
+    mp = PreparedMpqp(model["Huu"], model["Hux"], model["Hxx"], model["fu"], model["fx"], model["g"], model["Au"], model["Ax"], model["b"])
+    assert mp.large
+    X = rng.uniform(-1., 1., (16, p)) * 2.0
+    res = mp.solve_batch(X)
+    ref = oracle.mpqp_solve_batch(model, X)
+    st = res.numpy("status")
+    assert np.array_equal(st, ref["status"]) and (st == 0).any()
+    ok = st == 0
+    assert np.array_equal(res.active_mask()[ok], ref["active"][ok])
+    assert np.allclose(res.numpy("min")[ok], ref["min"][ok], rtol=1e-8, atol=1e-8)
+    assert np.allclose(res.numpy("argmin")[ok], ref["argmin"][ok], rtol=0, atol=1e-7)

@@ -196,3 +196,23 @@ def test_nnls_block_degenerate_inputs(oracle):
             if name in ("duplicate columns", "zero columns") and ro > 1e-9:
                 assert np.array_equal(x > 0, xo > 0), name
                 assert np.allclose(x, xo, atol=1e-9 * max(1.0, np.abs(xo).max())), name
+
+
+def test_few_rows_many_columns(oracle):
+    """More columns than the wave kernel takes with very few rows: the workgroup kernel with a handful of busy
+    row-threads; and the QP of one variable with 3000 constraints."""
+    from pympc_amd.optimization.solvers.hip_lp import nnls_batch
+    from pympc_amd.optimization.solvers.hip import quadratic_program
+    rng = np.random.RandomState(41)
+    for rows in (1, 2, 5):
+        A = rng.randn(3, rows, 3000); b = rng.randn(3, rows)
+        x, rn, st = nnls_batch(A, b)
+        x, rn = x.cpu().numpy(), rn.cpu().numpy()
+        assert (st.cpu().numpy() == 0).all()
+        for k in range(3):
+            xo, ro, _ = oracle.nnls(A[k], b[k])
+            assert abs(rn[k] - ro) < 1e-9 and x[k].min() >= 0.0 and abs(np.linalg.norm(A[k].dot(x[k]) - b[k]) - ro) < 1e-9
+    A = rng.randn(3000, 1); b = np.abs(rng.randn(3000)) + 0.5
+    ref = oracle.quadratic_program(np.array([[2.]]), np.array([-40.]), A, b)
+    sol = quadratic_program(np.array([[2.]]), np.array([-40.]), A, b)
+    assert abs(sol['min'] - ref['min']) < 1e-9 * max(1.0, abs(ref['min'])) and sol['active_set'] == ref['active_set']

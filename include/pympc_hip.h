@@ -253,7 +253,8 @@ int pympc_lp_solve_batch(int n, int m, int64_t B, const double *f, const double 
  * shared (a_stride 0); b [B x rows].  Outputs x [B x cols], rnorm [B] = |A x - b| (may be NULL), status [B]
  * (PYMPC_OPTIMAL / PYMPC_MAXITER: scipy raises RuntimeError there), iters [B x 2] (may be NULL).
  *
- * pympc_pnnls_batch: B problems  min |A_k v + B_k u - c_k|  s.t. v >= 0  (rows <= 1024, cols <= 32768, nu <= 64; beyond 64 rows also rows * nu * 8 bytes within the 160 KiB of LDS).
+ * pympc_pnnls_batch: B problems  min |A_k v + B_k u - c_k|  s.t. v >= 0  (rows <= 1024, cols <= 32768, nu <= 256; up to 64 of each on the
+ * wave kernel, beyond on the workgroup kernels of csrc/nnls_block.hpp, B in LDS while rows * nu * 8 bytes fit and nu <= 64).
  * Reference: pnnls(A, B, c) of pympc/optimization/solvers/pnnls.py:5-39 (returns v, u, r); the reference projects
  * with the dense matrix I - B pinv(B) (:30-33), here u is eliminated by a column-pivoted Householder QR of B (same
  * residual; u is the minimum-norm solution when B is rank deficient, as pinv gives).  A [B x rows x cols],

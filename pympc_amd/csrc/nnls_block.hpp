@@ -534,19 +534,24 @@ __global__ void __launch_bounds__(T) nnls_block_kernel(NnlsBlockParams P)
 // ---------------------------------------------------------------------------------------- PNNLS, 65 .. 1024 rows
 // pnnls_reduce_kernel of nnls_raw.hpp with one row per thread: Householder QR of B with column pivoting applied to
 // [A | c].  LDS: B (rows x (nu | 1)), the reflector, reduction slots, the permutation.
+constexpr int kPnnlsNuMax = 256;   // free variables (a thread per column of B)
+// BG: B itself stays in device memory (the caller's Rf region) instead of LDS -- more than 64 free variables, or
+// rows x nu beyond the LDS.
+__host__ __device__ inline size_t pnnls_block_lds_bytes_bg(int rows, int nu) { return ((size_t)rows + 32) * 8 + (size_t)(nu + 1) * 4; }
 __host__ __device__ inline size_t pnnls_block_lds_bytes(int rows, int nu)
 {
     return ((size_t)rows * (nu | 1) + rows + 32) * 8 + (size_t)(nu + 1) * 4;
 }
 
-template <int T>
+template <int T, bool BG>
 __global__ void __launch_bounds__(T) pnnls_reduce_block_kernel(PnnlsParams P)
 {
     constexpr int kBlkThreads = T;
     extern __shared__ double lds[];
     const long long k = blockIdx.x;
-    const int rows = P.rows, cols = P.cols, nu = P.nu, ld = nu | 1, t = threadIdx.x;
-    double *Bs = lds, *vv = Bs + (size_t)rows * ld, *slots = vv + rows;
+    const int rows = P.rows, cols = P.cols, nu = P.nu, ld = BG ? nu : (nu | 1), t = threadIdx.x;
+    double *Bs = BG ? P.Rf + k * (long long)rows * nu : lds;
+    double *vv = BG ? lds : Bs + (size_t)rows * ld, *slots = vv + rows;
     int *perm = reinterpret_cast<int *>(slots + 32);
     BlockReduce<T / 64> red{slots, 0};
     const double *A = P.A + k * (long long)rows * cols;
@@ -610,7 +615,8 @@ __global__ void __launch_bounds__(T) pnnls_reduce_block_kernel(PnnlsParams P)
         __syncthreads();
         rank = j + 1;
     }
-    for (int e = t; e < rows * nu; e += kBlkThreads) P.Rf[k * (long long)rows * nu + e] = Bs[(e / nu) * ld + (e % nu)];
+    if (!BG)
+        for (int e = t; e < rows * nu; e += kBlkThreads) P.Rf[k * (long long)rows * nu + e] = Bs[(e / nu) * ld + (e % nu)];
     if (t < nu) P.perm[k * nu + t] = perm[t];
     if (t == 0) P.rank[k] = rank;
 }

@@ -71,6 +71,7 @@ struct PnnlsParams {
     int32_t *rank;     // [B]
     const double *v;   // [B x cols] (recover kernel)
     double *u;         // [B x nu]   (recover kernel)
+    double *scr;       // recover kernel, nu > 64: [B x (nu (nu + 1) + 2 nu)] scratch in device memory (else null: LDS)
 };
 
 constexpr double kPnnlsRankTol = 1e-13;   // relative column norm below which the rest of B counts as dependent (pinv: rcond 1e-15 on singular values)
@@ -165,13 +166,15 @@ __global__ void __launch_bounds__(64) pnnls_recover_kernel(PnnlsParams P)
     const int rank = P.rank[k];
     const double *QA = P.QA + k * (long long)rows * cols;
     const double *Rf = P.Rf + k * (long long)rows * nu;
-    double *d = lds, *G = lds + 64, *t = G + 64 * 65;
-    if (lane < rank) {
-        double s = P.Qc[k * (long long)rows + lane];
-        for (int j = 0; j < cols; ++j) s = fma(-QA[(size_t)lane * cols + j], P.v[k * (long long)cols + j], s);
-        d[lane] = s;
+    // up to 64 free variables the small systems live in LDS, beyond in the caller's scratch (pitch gp)
+    const int NU = P.scr ? nu : 64, gp = NU + 1;
+    double *d = P.scr ? P.scr + k * ((long long)nu * (nu + 1) + 2 * nu) : lds, *G = d + NU, *t = G + (size_t)NU * gp;
+    for (int r = lane; r < rank; r += 64) {
+        double s = P.Qc[k * (long long)rows + r];
+        for (int j = 0; j < cols; ++j) s = fma(-QA[(size_t)r * cols + j], P.v[k * (long long)cols + j], s);
+        d[r] = s;
     }
-    if (lane < nu) P.u[k * nu + lane] = 0.0;
+    for (int j = lane; j < nu; j += 64) P.u[k * nu + j] = 0.0;
     __syncthreads();
     if (lane != 0 || rank == 0) return;
     const int32_t *perm = P.perm + k * nu;
@@ -190,24 +193,24 @@ __global__ void __launch_bounds__(64) pnnls_recover_kernel(PnnlsParams P)
         for (int b = 0; b <= a; ++b) {
             double s = 0.0;
             for (int j = 0; j < nu; ++j) s = fma(Rf[a * nu + j], Rf[b * nu + j], s);
-            G[a * 65 + b] = s;
+            G[a * gp + b] = s;
         }
     for (int a = 0; a < rank; ++a) {   // Cholesky, in place (lower)
         for (int b = 0; b <= a; ++b) {
-            double s = G[a * 65 + b];
-            for (int c2 = 0; c2 < b; ++c2) s = fma(-G[a * 65 + c2], G[b * 65 + c2], s);
-            G[a * 65 + b] = (a == b) ? sqrt(s) : s / G[b * 65 + b];
+            double s = G[a * gp + b];
+            for (int c2 = 0; c2 < b; ++c2) s = fma(-G[a * gp + c2], G[b * gp + c2], s);
+            G[a * gp + b] = (a == b) ? sqrt(s) : s / G[b * gp + b];
         }
     }
     for (int a = 0; a < rank; ++a) {
         double s = d[a];
-        for (int b = 0; b < a; ++b) s = fma(-G[a * 65 + b], t[b], s);
-        t[a] = s / G[a * 65 + a];
+        for (int b = 0; b < a; ++b) s = fma(-G[a * gp + b], t[b], s);
+        t[a] = s / G[a * gp + a];
     }
     for (int a = rank - 1; a >= 0; --a) {
         double s = t[a];
-        for (int b = a + 1; b < rank; ++b) s = fma(-G[b * 65 + a], t[b], s);
-        t[a] = s / G[a * 65 + a];
+        for (int b = a + 1; b < rank; ++b) s = fma(-G[b * gp + a], t[b], s);
+        t[a] = s / G[a * gp + a];
     }
     for (int j = 0; j < nu; ++j) {
         double s = 0.0;

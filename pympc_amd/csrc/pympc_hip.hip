@@ -608,27 +608,40 @@ int pympc_nnls_batch(int rows, int cols, int64_t B, const double *A, int64_t a_s
     return solve_common(false, R - 1, cols, 0, P, (hipStream_t)stream);
 }
 
+namespace {
+// doubles at the head of a PNNLS workspace that belong to its NNLS: the block kernel's when any of the three sizes sends
+// the problem there (more than 64 free variables do so even when the NNLS alone would fit the wave kernel)
+size_t pnnls_nnls_doubles(int rows, int cols, int nu, int64_t B)
+{
+    if (rows > 64 || cols > kMMax || nu > 64) {
+        if (rows > kBlkRowsMax || cols > kBlkColsMax) return 0;
+        return ((size_t)rows * cols + (size_t)rows * rows + 3 * (size_t)cols) * (size_t)B + 32;
+    }
+    return pympc_nnls_workspace_doubles(rows, cols, B);
+}
+}  // namespace
+
 size_t pympc_pnnls_workspace_doubles(int rows, int cols, int nu, int64_t B)
 {
-    if (rows < 1 || rows > kBlkRowsMax || cols < 1 || cols > kBlkColsMax || nu < 0 || nu > 64 || B < 0) return 0;
-    if ((rows > 64 || cols > kMMax) && pnnls_block_lds_bytes(rows, nu) > kLdsBytes) return 0;   // the reduction keeps B (rows x nu) in LDS
-    const size_t nn = pympc_nnls_workspace_doubles(rows, cols, B);
+    if (rows < 1 || rows > kBlkRowsMax || cols < 1 || cols > kBlkColsMax || nu < 0 || nu > kPnnlsNuMax || B < 0) return 0;
+    const size_t nn = pnnls_nnls_doubles(rows, cols, nu, B);
     if (nn == 0) return 0;
-    return nn + ((size_t)rows * cols + rows + (size_t)rows * nu + nu + 2) * (size_t)B + 32;
+    const size_t scr = nu > 64 ? (size_t)nu * (nu + 1) + 2 * (size_t)nu : 0;   // small systems of the recover kernel
+    return nn + ((size_t)rows * cols + rows + (size_t)rows * nu + nu + 2 + scr) * (size_t)B + 32;
 }
 
 int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, const double *Bm, const double *c, double *ws,
                       double *v, double *u, double *rnorm, int32_t *status, int32_t *iters, void *stream)
 {
     if (rows < 1 || cols < 1 || nu < 0 || B < 0) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: bad shape");
-    if (rows > kBlkRowsMax || nu > 64 || cols > kBlkColsMax || ((rows > 64 || cols > kMMax) && pnnls_block_lds_bytes(rows, nu) > kLdsBytes))
-        return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of %d rows, 64 free and %d sign-constrained variables "
-                    "(and rows x free variables within 160 KiB of LDS)", rows, cols, nu, kBlkRowsMax, kBlkColsMax);
+    if (rows > kBlkRowsMax || nu > kPnnlsNuMax || cols > kBlkColsMax)
+        return fail(PYMPC_ERR_UNSUPPORTED, "PNNLS %d x (%d + %d) exceeds the limits of %d rows, %d free and %d sign-constrained variables",
+                    rows, cols, nu, kBlkRowsMax, kPnnlsNuMax, kBlkColsMax);
     if (B == 0) return 0;
     if (!A || !c || !ws || !v || !status || (nu > 0 && (!Bm || !u))) return fail(PYMPC_ERR_ARG, "pympc_pnnls_batch: null pointer");
     if (nu == 0) return pympc_nnls_batch(rows, cols, B, A, (int64_t)rows * cols, c, ws, v, rnorm, status, iters, stream);
     if (B > 0x7fffffffLL) return fail(PYMPC_ERR_UNSUPPORTED, "batch too large");
-    const size_t nn = pympc_nnls_workspace_doubles(rows, cols, B);
+    const size_t nn = pnnls_nnls_doubles(rows, cols, nu, B);
     PnnlsParams R;
     memset(&R, 0, sizeof(R));
     R.rows = rows; R.cols = cols; R.nu = nu; R.A = A; R.Bm = Bm; R.c = c;
@@ -637,21 +650,22 @@ int pympc_pnnls_batch(int rows, int cols, int nu, int64_t B, const double *A, co
     R.Rf = R.Qc + (size_t)rows * B;
     R.perm = reinterpret_cast<int32_t *>(R.Rf + (size_t)rows * nu * B);
     R.rank = R.perm + (size_t)nu * B;
+    R.scr = nu > 64 ? reinterpret_cast<double *>(R.rank + (((size_t)B + 1) & ~(size_t)1)) : nullptr;
     R.v = v; R.u = u;
     hipStream_t st = (hipStream_t)stream;
-    if (rows > 64 || cols > kMMax) {   // one row per thread of a workgroup instead of one per lane (nnls_block.hpp)
-        const size_t ldsb = pnnls_block_lds_bytes(rows, nu);
+    if (rows > 64 || cols > kMMax || nu > 64) {   // one row per thread of a workgroup instead of one per lane (nnls_block.hpp)
+        const bool bg = nu > 64 || pnnls_block_lds_bytes(rows, nu) > kLdsBytes;   // B in device memory instead of LDS
+        const size_t ldsb = bg ? pnnls_block_lds_bytes_bg(rows, nu) : pnnls_block_lds_bytes(rows, nu);
         const int T = blk_threads(rows);
-        if (T == kBlkThreadsSmall) {
-            if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsSmall>, ldsb)) return rc;
-            hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsSmall>, dim3((unsigned)B), dim3(kBlkThreadsSmall), ldsb, st, R);
-        } else if (T == kBlkThreadsBig) {
-            if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsBig>, ldsb)) return rc;
-            hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsBig>, dim3((unsigned)B), dim3(kBlkThreadsBig), ldsb, st, R);
-        } else {
-            if (int rc = allow_lds(pnnls_reduce_block_kernel<kBlkThreadsHuge>, ldsb)) return rc;
-            hipLaunchKernelGGL(pnnls_reduce_block_kernel<kBlkThreadsHuge>, dim3((unsigned)B), dim3(kBlkThreadsHuge), ldsb, st, R);
-        }
+#define PYMPC_LAUNCH_PNNLS_REDUCE(TT, BGV)                                                                       \
+    do {                                                                                                         \
+        if (int rc = allow_lds(pnnls_reduce_block_kernel<TT, BGV>, ldsb)) return rc;                             \
+        hipLaunchKernelGGL((pnnls_reduce_block_kernel<TT, BGV>), dim3((unsigned)B), dim3(TT), ldsb, st, R);      \
+    } while (0)
+        if (T == kBlkThreadsSmall) { if (bg) PYMPC_LAUNCH_PNNLS_REDUCE(kBlkThreadsSmall, true); else PYMPC_LAUNCH_PNNLS_REDUCE(kBlkThreadsSmall, false); }
+        else if (T == kBlkThreadsBig) { if (bg) PYMPC_LAUNCH_PNNLS_REDUCE(kBlkThreadsBig, true); else PYMPC_LAUNCH_PNNLS_REDUCE(kBlkThreadsBig, false); }
+        else { if (bg) PYMPC_LAUNCH_PNNLS_REDUCE(kBlkThreadsHuge, true); else PYMPC_LAUNCH_PNNLS_REDUCE(kBlkThreadsHuge, false); }
+#undef PYMPC_LAUNCH_PNNLS_REDUCE
         if (int rc = check_launch("pnnls_reduce_block_kernel")) return rc;
         if (int rc = launch_nnls_block(rows, cols, B, R.QA, (int64_t)rows * cols, R.Qc, rows, R.rank, ws, v, rnorm, status, iters, st)) return rc;
         hipLaunchKernelGGL(pnnls_recover_kernel, dim3((unsigned)B), dim3(64), (64 + 64 * 65 + 64) * 8, st, R);

@@ -78,6 +78,11 @@ def linear_program(f, A, b, C=None, d=None, tol=TOL):
         bd = np.concatenate((b, d, -d))
     else:
         AC, bd = A, b
+    n_lp, m_lp = _hip.lp_limits()
+    if f.size > n_lp and f.size <= 256 and 1 + AC.shape[0] + f.size <= 1024:
+        # more variables than the active-set kernel's factor holds (a lane per row of it): the reference's own KKT form
+        # on the workgroup-per-problem PNNLS kernels
+        return linear_program_pnnls(f, A, b, C, d, tol=tol)
     res = linear_program_batch(f[None, :], AC, bd, tol=tol, n_eq=n_eq)
     if int(res.t['status'][0].item()) == _hip.MAXITER:
         # The active-set kernel can stall on a dual-degenerate LP (an objective that does not see most variables: the
@@ -165,7 +170,7 @@ def pnnls_batch(A, B, c):
     nu = Bm.shape[2]
     nd = lib.pympc_pnnls_workspace_doubles(rows, cols, nu, Bn)
     if nd == 0:
-        raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (1024 rows, 32768 + 64; rows x free variables within 160 KiB of LDS)'
+        raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (1024 rows, 32768 + 256)'
                                   % (rows, cols, nu))
     ws = torch.empty(nd, dtype=torch.float64, device=dev)
     v = torch.empty((Bn, cols), dtype=torch.float64, device=dev)
@@ -188,7 +193,8 @@ def pnnls(A, B, c):
 
 def linear_program_pnnls(f, A, b, C=None, d=None, tol=TOL):
     """The reference's own LP formulation on the device, for LPs of 1 + m + n <= 1024 rows after folding equalities and
-    n <= 64 (up to 64 rows on the wave kernel, beyond on the workgroup-per-problem kernel of csrc/nnls_block.hpp):
+    n <= 256 (up to 64 rows and variables on the wave kernel, beyond on the workgroup-per-problem kernels of
+    csrc/nnls_block.hpp):
     the KKT system of pnnls.py:109-124 solved by pnnls(), solvable iff the residual is below tol (pnnls.py:137).
     linear_program() reaches the same primal-dual pair with a dual active-set method in n-space and decides
     feasibility row by row (violation above 1e-9 max(1, |b_j|)); the two decisions differ only for LPs that are

@@ -39,7 +39,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.pympc_mpqp_multi_workspace_doubles(63, 100, 8, 10) == 0
     assert lib.pympc_nnls_workspace_doubles(64, 2048, 3) > 0 and lib.pympc_nnls_workspace_doubles(1025, 10, 3) == 0
     assert lib.pympc_nnls_workspace_doubles(65, 10, 3) >= 65 * 10 * 3             # 65 .. 1024 rows: a working copy per problem
-    assert lib.pympc_pnnls_workspace_doubles(64, 100, 64, 2) > 0 and lib.pympc_pnnls_workspace_doubles(64, 100, 65, 2) == 0
+    assert lib.pympc_pnnls_workspace_doubles(64, 100, 64, 2) > 0 and lib.pympc_pnnls_workspace_doubles(64, 100, 257, 2) == 0
+    assert lib.pympc_pnnls_workspace_doubles(64, 100, 65, 2) > lib.pympc_pnnls_workspace_doubles(64, 100, 64, 2)   # 65 .. 256 free variables: workgroup kernels
 
 
 def test_no_gpu_means_loud_failure():

@@ -101,7 +101,8 @@ def test_nnls_block_iteration_limit():
 def test_pnnls_block_random_vs_oracle(oracle):
     from pympc_amd.optimization.solvers.hip_lp import pnnls, pnnls_batch
     rng = np.random.RandomState(6)
-    for rows, nv, nu in ((65, 40, 3), (100, 150, 20), (128, 60, 64), (200, 300, 10), (256, 100, 33), (300, 150, 40), (512, 200, 30), (900, 300, 12)):
+    for rows, nv, nu in ((65, 40, 3), (100, 150, 20), (128, 60, 64), (200, 300, 10), (256, 100, 33), (300, 150, 40), (512, 200, 30), (900, 300, 12),
+                         (100, 50, 65), (300, 200, 128), (600, 100, 256), (40, 30, 70), (1024, 50, 200)):
         A = rng.randn(rows, nv); B = rng.randn(rows, nu); c = rng.randn(rows)
         v, u, r = pnnls(A, B, c)
         vo, uo, ro = oracle.pnnls(A, B, c)
@@ -115,6 +116,11 @@ def test_pnnls_block_random_vs_oracle(oracle):
     v, u, r = pnnls(A, B, c)
     vo, uo, ro = oracle.pnnls(A, B, c)
     assert np.allclose(v, vo, atol=1e-8) and np.allclose(u, uo, atol=1e-8) and abs(r - ro) < 1e-9
+    # rank-deficient B with more than 64 columns (the recover kernel's systems in device scratch)
+    A = rng.randn(150, 40); B0 = rng.randn(150, 60); B = np.column_stack((B0, B0[:, :20] - B0[:, 20:40], np.zeros((150, 3)))); c = rng.randn(150)
+    v, u, r = pnnls(A, B, c)
+    vo, uo, ro = oracle.pnnls(A, B, c)
+    assert abs(r - ro) < 1e-9 and np.allclose(v, vo, atol=1e-8) and np.allclose(u, uo, atol=1e-7 * max(1.0, np.abs(uo).max()))
     # batch
     A = rng.randn(5, 77, 50); B = rng.randn(5, 77, 6); c = rng.randn(5, 77)
     v, u, rn, st = pnnls_batch(A, B, c)
@@ -162,6 +168,16 @@ def test_lp_in_the_reference_form_beyond_64_rows(oracle):
             ref = oracle.linear_program(f, A2, b2); sol = linear_program_pnnls(f, A2, b2)
             assert (sol['min'] is None) == (ref['min'] is None), (n, m, gap)
     assert n_solv >= 4
+    # more variables than the active-set LP kernel takes: linear_program itself goes to the KKT form
+    from pympc_amd.optimization.solvers.hip_lp import linear_program as lp_scalar
+    for n, m in ((80, 200), (150, 320)):
+        A = np.vstack((rng.randn(m - 2 * n, n), np.eye(n), -np.eye(n))); b = np.concatenate((rng.rand(m - 2 * n) + 0.5, np.ones(2 * n)))
+        f = rng.randn(n)
+        ref = oracle.linear_program(f, A, b); sol = lp_scalar(f, A, b)
+        assert ref['min'] is not None and abs(sol['min'] - ref['min']) < 1e-7 * max(1.0, abs(ref['min']))
+        assert np.allclose(sol['argmin'], ref['argmin'], atol=1e-6) and sol['active_set'] == ref['active_set']
+        A2 = np.vstack((A, -np.eye(n)[0])); b2 = np.concatenate((b, [-1.5]))          # x_0 >= 1.5 against x_0 <= 1
+        assert lp_scalar(f, A2, b2)['min'] is None and oracle.linear_program(f, A2, b2)['min'] is None
     # the same through the dispatch of optimization/programs.py
     from pympc_amd.optimization.programs import linear_program
     sol = linear_program(f, A, b, solver='hip_kkt'); ref = oracle.linear_program(f, A, b)

@@ -354,7 +354,8 @@ class Polyhedron(object):
         """
         Bounded iff ker(A) = 0 and the polyhedron has no recession direction (polyhedron.py:528-576).  The reference
         decides the second part with Stiemke's alternative, an LP with one variable per ROW of A (some y >= 1 with
-        A'y = 0); that LP is used here while it fits the LP kernel (rows <= 64 variables).  Beyond that the same decision
+        A'y = 0); that LP is used here while it fits the LP paths (up to 64 rows on the active-set kernel, up to 256 rows with
+        1 + 2 rows + 2 dim <= 1024 in the reference's KKT form on the workgroup kernels).  Beyond that the same decision
         is taken in the primal space: a non-empty polyhedron is bounded iff the 2 dim LPs max +-x_i over it all have an
         optimum (one batched launch against the shared constraint matrix).
         """
@@ -368,7 +369,8 @@ class Polyhedron(object):
         n, m = A.shape
         from .. import _hip
         n_lp_max = _hip.lp_limits()[0]
-        if n <= n_lp_max:
+        if n <= n_lp_max or (n <= 256 and 1 + 2 * n + 2 * m <= 1024):
+            # (beyond the LP kernel's 64 variables linear_program solves the reference's KKT form on the workgroup kernels)
             sol = linear_program(np.ones(n), -np.eye(n), -np.ones(n), A.T, np.zeros(m))
             self._bounded = sol['min'] is not None
         elif m <= n_lp_max:

@@ -199,3 +199,20 @@ def test_mpqp_with_more_constraints_than_the_prepared_form_takes(oracle):
     assert np.array_equal(res.active_mask()[ok], ref["active"][ok])
     assert np.allclose(res.numpy("min")[ok], ref["min"][ok], rtol=1e-8, atol=1e-8)
     assert np.allclose(res.numpy("argmin")[ok], ref["argmin"][ok], rtol=0, atol=1e-7)
+
+
+def test_bounded_with_more_than_64_rows_and_dimensions():
+    """Polyhedron.bounded by Stiemke's LP (polyhedron.py:528-576) for a polytope with 150 rows in 70 dimensions: refused
+    while the LP paths ended at 64 variables."""
+    from pympc_amd.geometry.polyhedron import Polyhedron
+    rng = np.random.RandomState(3)
+    n = 70
+    box = Polyhedron.from_bounds(-np.ones(n), np.ones(n))
+    extra = rng.randn(10, n)
+    P = Polyhedron(np.vstack((box.A, extra)), np.concatenate((box.b, np.full(10, 20.0))))
+    assert P.bounded
+    keep = np.ones(box.A.shape[0], bool)
+    keep[int(np.where((box.A[:, 0] > 0.5))[0][0])] = False           # drop x_0 <= 1 ...
+    more = np.zeros((10, n)); more[:, 0] = -1.0                      # ... and add ten rows -x_0 <= 20: the ray along +x_0 stays
+    Q = Polyhedron(np.vstack((box.A[keep], more)), np.concatenate((box.b[keep], np.full(10, 20.0))))
+    assert not Q.bounded

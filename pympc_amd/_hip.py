@@ -98,6 +98,26 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Kernel scratch of the batched calls (the `ws` argument of the C ABI: overwritten from its first use on, never read by
+# the caller): one grow-only tensor per (device, stream) instead of an allocation per call.  Launches on one stream run
+# in order, so the next call's kernels only touch it after this call's are done; calls on different streams get
+# different tensors.  Large requests (a whole batch of per-problem workspaces) are not kept.
+_SCRATCH = {}
+SCRATCH_KEEP_DOUBLES = 1 << 23     # 64 MiB
+
+
+def scratch(nd):
+    dev = device()
+    if nd > SCRATCH_KEEP_DOUBLES:
+        return torch.empty(nd, dtype=torch.float64, device=dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nd:
+        t = torch.empty(min(SCRATCH_KEEP_DOUBLES, max(nd, 2 * (0 if t is None else t.numel()))), dtype=torch.float64, device=dev)
+        _SCRATCH[key] = t
+    return t
+
+
 def to_device(a, dtype=torch.float64):
     """numpy / torch -> contiguous device tensor (no copy if already there)."""
     if isinstance(a, torch.Tensor):

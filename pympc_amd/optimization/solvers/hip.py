@@ -352,7 +352,7 @@ def quadratic_program_batch(H, f, A, b, tol=TOL, n_eq=0, want_mult=True, want_ac
         nmax, mmax = _hip.limits()
         raise NotImplementedError('QP with n=%d, m=%d is outside the kernel limits (n<=%d on the wave kernel, n<=1023 on the '
                                   'workgroup kernel of csrc/qp_block.hpp; m<=%d on the wave kernel, m<=32768 beyond)' % (n, m, nmax, mmax))
-    ws = torch.empty(nd, dtype=torch.float64, device=dev)
+    ws = _hip.scratch(nd)
     out = _alloc_outputs(B, n, m, dev, want_mult, want_active, want_iters)
     _hip.check(lib.pympc_qp_solve_batch(n, m, B, _hip.ptr(H), h_stride, _hip.ptr(f), _hip.ptr(A), a_stride, _hip.ptr(b),
                                         float(tol), _hip.ptr(ws), _hip.ptr(out['argmin']), _hip.ptr(out['min']),

@@ -46,7 +46,7 @@ def linear_program_batch(f, A, b, tol=TOL, n_eq=0, relax_idx=None, relax_val=0.,
     if nd == 0:
         raise NotImplementedError('LP with n=%d, m=%d is outside the LP kernel limits (n<=%d, m<=%d)'
                                   % ((n, m) + _hip.lp_limits()))
-    ws = torch.empty(nd, dtype=torch.float64, device=dev)
+    ws = _hip.scratch(nd)
     rx = None if relax_idx is None else _hip.to_device(relax_idx, dtype=torch.int32)
     f64 = dict(dtype=torch.float64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -140,7 +140,7 @@ def nnls_batch(A, b):
     if nd == 0:
         raise NotImplementedError('NNLS with %d rows, %d columns is outside the kernel limits (1024 rows, 32768 columns)'
                                   % (rows, cols))
-    ws = torch.empty(nd, dtype=torch.float64, device=dev)
+    ws = _hip.scratch(nd)
     x = torch.empty((B, cols), dtype=torch.float64, device=dev)
     rn = torch.empty(B, dtype=torch.float64, device=dev)
     st = torch.empty(B, dtype=torch.int32, device=dev)
@@ -172,7 +172,7 @@ def pnnls_batch(A, B, c):
     if nd == 0:
         raise NotImplementedError('PNNLS with %d rows, %d + %d variables is outside the kernel limits (1024 rows, 32768 + 256)'
                                   % (rows, cols, nu))
-    ws = torch.empty(nd, dtype=torch.float64, device=dev)
+    ws = _hip.scratch(nd)
     v = torch.empty((Bn, cols), dtype=torch.float64, device=dev)
     u = torch.empty((Bn, nu), dtype=torch.float64, device=dev)
     rn = torch.empty(Bn, dtype=torch.float64, device=dev)

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and streams; every kernel is our
 if the HIP library or a GPU is missing the product path raises.
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -100,8 +101,9 @@ def stream_ptr():
 
 # Kernel scratch of the batched calls (the `ws` argument of the C ABI: overwritten from its first use on, never read by
 # the caller): one grow-only tensor per (device, stream) instead of an allocation per call.  Launches on one stream run
-# in order, so the next call's kernels only touch it after this call's are done; calls on different streams get
-# different tensors.  Large requests (a whole batch of per-problem workspaces) are not kept.
+# in order, so the next call's kernels only touch it after this call's are done; calls on different streams, or from
+# different Python threads (ctypes drops the GIL during a call, so two threads' launches can interleave on one stream),
+# get different tensors.  Large requests (a whole batch of per-problem workspaces) are not kept.
 _SCRATCH = {}
 SCRATCH_KEEP_DOUBLES = 1 << 23     # 64 MiB
 
@@ -110,7 +112,7 @@ def scratch(nd):
     dev = device()
     if nd > SCRATCH_KEEP_DOUBLES:
         return torch.empty(nd, dtype=torch.float64, device=dev)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident())
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nd:
         t = torch.empty(min(SCRATCH_KEEP_DOUBLES, max(nd, 2 * (0 if t is None else t.numel()))), dtype=torch.float64, device=dev)

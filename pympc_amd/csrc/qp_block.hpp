@@ -144,23 +144,44 @@ __global__ void __launch_bounds__(T) qp_block_prepare_kernel(QpBlockParams P)
         hs[t] = s;
     }
     __syncthreads();
-    // the NNLS matrix, a constraint row per thread
-    for (int r = t; r < m; r += kBlkThreads) {
-        // eight columns of M at a time: one pass over the row of A for eight sums (the entries of L^-1 above its
-        // diagonal are stored zeros, which add nothing: the sums are those of the loop q <= c)
-        for (int c0 = 0; c0 < n; c0 += 8) {
-            double sv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            const int cl = c0 + 8 <= n ? c0 + 7 : n - 1;
-            for (int q = 0; q <= cl; ++q) {
+    // The NNLS matrix, a constraint row per thread and kCb columns of M at a time: the kCb rows of L^-1 staged in LDS (read
+    // as broadcasts), the row of A loaded eight entries at a time; the entries of L^-1 above its diagonal are stored
+    // zeros, which add nothing: the sums are those of the loop q <= c, in the same order.
+    constexpr int kCb = T >= 1024 ? 4 : 8;
+    __shared__ double lib[kCb * T];
+    for (int c0 = 0; c0 < n; c0 += kCb) {
+        const int cl = c0 + kCb <= n ? c0 + kCb - 1 : n - 1, nq = cl + 1;
+        __syncthreads();
+        for (int e = t; e < kCb * nq; e += kBlkThreads) {
+            const int u = e / nq, q = e - u * nq;
+            lib[u * T + q] = c0 + u < n ? Li[(size_t)(c0 + u) * n + q] : 0.0;
+        }
+        __syncthreads();
+        for (int r = t; r < m; r += kBlkThreads) {
+            double sv[kCb];
+#pragma unroll
+            for (int u = 0; u < kCb; ++u) sv[u] = 0.0;
+            int q = 0;
+            for (; q + 8 <= nq; q += 8) {
+                double av[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) av[w] = At[(size_t)(q + w) * m + r];
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+#pragma unroll
+                    for (int u = 0; u < kCb; ++u) sv[u] = fma(av[w], lib[u * T + q + w], sv[u]);
+            }
+            for (; q < nq; ++q) {
                 const double av = At[(size_t)q * m + r];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (c0 + u < n) sv[u] = fma(av, Li[(size_t)(c0 + u) * n + q], sv[u]);
+                for (int u = 0; u < kCb; ++u) sv[u] = fma(av, lib[u * T + q], sv[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < kCb; ++u)
                 if (c0 + u < n) An[(size_t)(c0 + u) * m + r] = -sv[u];
         }
+    }
+    for (int r = t; r < m; r += kBlkThreads) {
         double s = 0.0;
         for (int q = 0; q < n; ++q) s = fma(At[(size_t)q * m + r], hs[q], s);
         s += b[r];
